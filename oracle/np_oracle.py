@@ -1,0 +1,242 @@
+"""Independent NumPy/SciPy restatement of the same algorithms as vqa_oracle.c.
+
+TEST INFRASTRUCTURE ONLY.  Exists so the C oracle is checked against a second,
+differently-structured formulation (vectorised NMS + connected-component
+labelling instead of a stack walk, scipy.fft instead of a cosine-matrix product,
+candidate-major SAD instead of block-major, correlate1d instead of nested
+loops).  Citations are to the reference call sites each function stands in for.
+"""
+import numpy as np
+import scipy.fft
+import scipy.ndimage
+
+
+# cv2.cvtColor(BGR2GRAY) — complexity_metrics.py:327-328,358,405,493,530
+def bgr2gray(bgr):
+    b = bgr[..., 0].astype(np.int64)
+    g = bgr[..., 1].astype(np.int64)
+    r = bgr[..., 2].astype(np.int64)
+    return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+def _tables(ssize, dsize, is_x):
+    d = np.arange(dsize, dtype=np.float64)
+    scale = 1.0 / (np.float64(dsize) / np.float64(ssize))
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int32)
+    f = f - s.astype(np.float32)
+    if is_x:
+        lo = s < 0
+        f[lo] = 0
+        s[lo] = 0
+        hi = s >= ssize - 1
+        f[hi] = 0
+        s[hi] = ssize - 1
+    a0 = np.rint((np.float32(1.0) - f) * np.float32(2048)).astype(np.int32)
+    a1 = np.rint(f * np.float32(2048)).astype(np.int32)
+    return s, a0, a1
+
+
+# cv2.resize default INTER_LINEAR — complexity_metrics.py:359,404,430,490,531
+def resize_linear(img, dw, dh):
+    sh, sw = img.shape[:2]
+    if (sh, sw) == (dh, dw):
+        return img.copy()
+    x = img.reshape(sh, sw, -1).astype(np.int64)
+    if sw == 2 * dw and sh == 2 * dh:
+        out = (x[0::2, 0::2] + x[0::2, 1::2] + x[1::2, 0::2] + x[1::2, 1::2] + 2) >> 2
+        return out.astype(np.uint8).reshape((dh, dw) + img.shape[2:])
+    sx, a0, a1 = _tables(sw, dw, True)
+    sy, b0, b1 = _tables(sh, dh, False)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    rows = x[:, sx, :] * a0[None, :, None] + x[:, sx1, :] * a1[None, :, None]  # (sh, dw, cn)
+    y0 = np.clip(sy, 0, sh - 1)
+    y1 = np.clip(sy + 1, 0, sh - 1)
+    s0 = rows[y0] >> 4
+    s1 = rows[y1] >> 4
+    out = (((b0[:, None, None] * s0) >> 16) + ((b1[:, None, None] * s1) >> 16) + 2) >> 2
+    return out.astype(np.uint8).reshape((dh, dw) + img.shape[2:])
+
+
+# cv2.dct(np.float32(x)) — complexity_metrics.py:363,574-575
+def dct2_full(x):
+    return scipy.fft.dctn(np.asarray(x, np.float64), norm="ortho")
+
+
+def dct8x8_blocks(gray):
+    h, w = gray.shape
+    hp, wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+    p = np.zeros((hp, wp), np.float64)
+    p[:h, :w] = gray
+    b = p.reshape(hp // 8, 8, wp // 8, 8).transpose(0, 2, 1, 3)
+    return scipy.fft.dctn(b, axes=(2, 3), norm="ortho")
+
+
+def dct8x8(prev, curr):
+    cc = dct8x8_blocks(curr)
+    e = float(np.sum(cc * cc))
+    l1 = float(np.sum(np.abs(dct8x8_blocks(prev) - cc))) if prev is not None else 0.0
+    return e, l1
+
+
+# cv2.calcHist — complexity_metrics.py:412,455-457
+def hist_u8(a):
+    return np.bincount(np.asarray(a, np.uint8).reshape(-1), minlength=256).astype(np.uint32)
+
+
+# entropy tails, verbatim arithmetic of complexity_metrics.py:412-414 / :467-473 on float32 hists
+def gray_entropy_from_counts(counts):
+    hist = np.asarray(counts, np.float32).reshape(256, 1)
+    hist = hist / hist.sum()
+    return -np.sum(hist[hist > 0] * np.log2(hist[hist > 0]))
+
+
+def color_entropy_from_counts(counts_bgr):
+    hs = [np.asarray(c, np.float32).reshape(256, 1) for c in counts_bgr]
+    sums = [h.sum() for h in hs]
+    if sums[0] == 0 or sums[1] == 0 or sums[2] == 0:
+        return float("nan")
+    hs = [h / s for h, s in zip(hs, sums)]
+    return -(np.sum(hs[0] * np.log2(hs[0] + 1e-8)) + np.sum(hs[1] * np.log2(hs[1] + 1e-8)) +
+             np.sum(hs[2] * np.log2(hs[2] + 1e-8)))
+
+
+# cv2.Canny(gray, 100, 200) — complexity_metrics.py:503-504
+def canny(gray, low=100, high=200):
+    g = np.pad(gray.astype(np.int32), 1, mode="edge")
+    h, w = gray.shape
+    def s(dy, dx):
+        return g[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+    gx = (s(-1, 1) + 2 * s(0, 1) + s(1, 1)) - (s(-1, -1) + 2 * s(0, -1) + s(1, -1))
+    gy = (s(1, -1) + 2 * s(1, 0) + s(1, 1)) - (s(-1, -1) + 2 * s(-1, 0) + s(-1, 1))
+    mag = np.abs(gx) + np.abs(gy)
+    mp = np.pad(mag, 1, mode="constant")
+    def m(dy, dx):
+        return mp[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+    ax = np.abs(gx).astype(np.int64)
+    ay = np.abs(gy).astype(np.int64) << 15
+    tg22 = ax * 13573
+    tg67 = tg22 + (ax << 16)
+    horiz = ay < tg22
+    vert = (~horiz) & (ay > tg67)
+    diag = ~(horiz | vert)
+    opposite = (gx.astype(np.int16) ^ gy.astype(np.int16)) < 0
+    keep_h = (mag > m(0, -1)) & (mag >= m(0, 1))
+    keep_v = (mag > m(-1, 0)) & (mag >= m(1, 0))
+    keep_d_same = (mag > m(-1, -1)) & (mag > m(1, 1))
+    keep_d_opp = (mag > m(-1, 1)) & (mag > m(1, -1))
+    keep = (mag > low) & ((horiz & keep_h) | (vert & keep_v) |
+                          (diag & ~opposite & keep_d_same) | (diag & opposite & keep_d_opp))
+    strong = keep & (mag > high)
+    lab, n = scipy.ndimage.label(keep, structure=np.ones((3, 3), int))
+    if n == 0:
+        return 0, 0, 0, np.zeros((h, w), np.uint8)
+    has_strong = np.zeros(n + 1, bool)
+    has_strong[np.unique(lab[strong])] = True
+    has_strong[0] = False
+    edges = has_strong[lab]
+    return int(edges.sum()), int(strong.sum()), int((keep & ~strong).sum()), (edges * 255).astype(np.uint8)
+
+
+# block-SAD motion (substitute for complexity_metrics.py:313-343; spec in vqa_oracle.c)
+def block_sad(prev, curr, rng=7):
+    h, w = curr.shape
+    nby, nbx = h // 16, w // 16
+    if nby == 0 or nbx == 0:
+        return 0, 0, np.zeros(129, np.uint32), np.zeros((0, 2), np.int8)
+    c = curr[:nby * 16, :nbx * 16].astype(np.int32)
+    P = prev.astype(np.int32)
+    best = np.full((nby, nbx), np.iinfo(np.int64).max, np.int64)
+    best_mv = np.zeros((nby, nbx, 2), np.int8)
+    by = np.arange(nby)[:, None] * 16
+    bx = np.arange(nbx)[None, :] * 16
+    for dy in range(-rng, rng + 1):
+        for dx in range(-rng, rng + 1):
+            valid = (by + dy >= 0) & (by + 16 + dy <= h) & (bx + dx >= 0) & (bx + 16 + dx <= w)
+            # shifted prev, out-of-frame samples never used by a valid block
+            sh = np.zeros_like(c)
+            ys = np.arange(nby * 16) + dy
+            xs = np.arange(nbx * 16) + dx
+            yv = (ys >= 0) & (ys < h)
+            xv = (xs >= 0) & (xs < w)
+            sh[np.ix_(yv, xv)] = P[np.ix_(ys[yv], xs[xv])]
+            sad = np.abs(c - sh).reshape(nby, 16, nbx, 16).sum(axis=(1, 3)).astype(np.int64)
+            d2 = dy * dy + dx * dx
+            ridx = (dy + 8) * 16 + (dx + 8)
+            key = (sad << 16) | (d2 << 8) | ridx
+            key[~valid] = np.iinfo(np.int64).max
+            upd = key < best
+            best[upd] = key[upd]
+            best_mv[upd] = (dy, dx)
+    sad_sum = int((best >> 16).sum())
+    d2 = (best_mv.astype(np.int32) ** 2).sum(axis=2)
+    hist = np.bincount(d2.reshape(-1), minlength=129).astype(np.uint32)
+    return nby * nbx, sad_sum, hist, best_mv.reshape(-1, 2)
+
+
+def motion_mag_from_hist(d2_hist, nblocks):
+    if nblocks == 0:
+        return 0.0
+    k = np.arange(129, dtype=np.float64)
+    return float(np.sum(np.asarray(d2_hist, np.float64) * np.sqrt(k)) / nblocks)
+
+
+# PSNR pieces (FFmpeg vf_psnr) / SSIM — video_processing.py:275-276
+def sse_plane(a, b):
+    d = a.astype(np.int64) - b.astype(np.int64)
+    return int(np.sum(d * d))
+
+
+def gauss11():
+    k = np.arange(11, dtype=np.float64) - 5
+    g = np.exp(-(k * k) / (2 * 1.5 * 1.5))
+    return g / g.sum()
+
+
+def ssim_gauss(a, b):
+    g = gauss11().astype(np.float32).astype(np.float64)
+    x = a.astype(np.float64)
+    y = b.astype(np.float64)
+    def filt(z):
+        z = scipy.ndimage.correlate1d(z, g, axis=0, mode="constant")
+        z = scipy.ndimage.correlate1d(z, g, axis=1, mode="constant")
+        return z[5:-5, 5:-5]
+    mx, my = filt(x), filt(y)
+    xx, yy, xy = filt(x * x), filt(y * y), filt(x * y)
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    vx, vy, cxy = xx - mx * mx, yy - my * my, xy - mx * my
+    s = ((2 * mx * my + c1) * (2 * cxy + c2)) / ((mx * mx + my * my + c1) * (vx + vy + c2))
+    return float(s.mean())
+
+
+def ssim_ffmpeg(a, b):
+    h, w = a.shape
+    bh, bw = h >> 2, w >> 2
+    x = a[:bh * 4, :bw * 4].astype(np.int64).reshape(bh, 4, bw, 4)
+    y = b[:bh * 4, :bw * 4].astype(np.int64).reshape(bh, 4, bw, 4)
+    s1 = x.sum(axis=(1, 3)); s2 = y.sum(axis=(1, 3))
+    ss = (x * x).sum(axis=(1, 3)) + (y * y).sum(axis=(1, 3))
+    s12 = (x * y).sum(axis=(1, 3))
+    def pool(s):
+        return s[:-1, :-1] + s[:-1, 1:] + s[1:, :-1] + s[1:, 1:]
+    s1, s2, ss, s12 = pool(s1), pool(s2), pool(ss), pool(s12)
+    c1 = int(.01 * .01 * 255 * 255 * 64 + .5)
+    c2 = int(.03 * .03 * 255 * 255 * 64 * 63 + .5)
+    vars_ = ss * 64 - s1 * s1 - s2 * s2
+    covar = s12 * 64 - s1 * s2
+    f = np.float32
+    v = (f(2 * s1 * s2 + c1) * f(2 * covar + c2)) / (f(s1 * s1 + s2 * s2 + c1) * f(vars_ + c2))
+    return float(v.astype(np.float64).mean())
+
+
+# pandas .ewm(alpha, adjust=True).mean() — complexity_metrics.py:125
+def ewm_mean(x, alpha=0.8):
+    x = np.asarray(x, np.float64)
+    out = np.empty_like(x)
+    num = 0.0
+    den = 0.0
+    for i, v in enumerate(x):
+        num = num * (1 - alpha) + v
+        den = den * (1 - alpha) + 1.0
+        out[i] = num / den
+    return out
