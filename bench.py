@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the hot path on synthetic frame streams, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W                  (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W   (N > 1, one rank per GPU)
+
+A "step" is one pass of the selected workload over one device-resident batch of
+frames.  Rank 0 prints ONE JSON line (contract in the task statement) with two
+extra objects: "roofline" (dominant kernel, algorithmic bytes / HIP-event time)
+and, at N = 1, "cpu_baseline" (the oracle port under a process pool that
+reproduces the reference's process_in_batches, timed on this box's host cores).
+
+Workloads (BASELINE.json configs):
+  c2  1920x1080, frame_interval=1, PSNR + SSIM (Gaussian) + 8x8 DCT (energy + temporal)   [default]
+  c3  1920x1080 full complexity suite + PSNR/SSIM
+  c4  3840x2160 full suite
+Frame streams shard one-stream-per-GPU (weak scaling): every rank runs the same
+workload on its own stream; the only cross-rank traffic is one scalar
+all-reduce (RCCL) of the pooled metrics after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "c2": dict(h=1080, w=1920, batch=256, full=False,
+               name="1920x1080 frame_interval=1 PSNR+SSIM(gauss 11x11)+8x8 DCT(energy+temporal), BGR24 pairs"),
+    "c3": dict(h=1080, w=1920, batch=256, full=True,
+               name="1920x1080 full suite (motion-SAD, DCT, temporal-DCT, Canny, gray+colour hist) + PSNR/SSIM"),
+    "c4": dict(h=2160, w=3840, batch=64, full=True, name="3840x2160 full suite + PSNR/SSIM"),
+}
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline: oracle port, dispatcher = the reference's process_in_batches
+# (ProcessPoolExecutor, executor.map chunksize 1 => one pickle per item).
+# ---------------------------------------------------------------------------
+def _cpu_item(item):
+    from oracle import c_oracle as co
+    from oracle import pipeline as pl
+    from rtvqa_amd.engine import bgr_planes
+    ref, dist, prev, full = item
+    h, w = dist.shape[:2]
+    out = []
+    sse, ssim = pl.frame_quality(ref, dist, bgr_planes(h, w), "gauss")
+    out += sse + ssim
+    g, gp = co.bgr2gray(dist), co.bgr2gray(prev)
+    out += list(co.dct8x8(gp, g)[:2])
+    if full:
+        out.append(co.canny(g, 100, 200)[0])
+        out += list(co.block_sad(gp, g, 7)[:2])
+        out.append(int(co.hist_u8(g).sum()))
+        out += [int(co.hist_u8(dist, offset=c, step=3).sum()) for c in range(3)]
+    return out
+
+
+def cpu_baseline(ref, dist, full, sample):
+    from concurrent.futures import ProcessPoolExecutor
+    from oracle import c_oracle as co
+    co.build()
+    cores = os.cpu_count() or 1
+    workers = max(1, cores // 2)  # complexity_metrics.py:264-265
+    items = [(ref[i], dist[i], dist[i - 1] if i else dist[0], full) for i in range(sample)]
+    t0 = time.perf_counter()
+    results = []
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        for i in range(0, len(items), 100):  # batch_size=100, barrier per batch (:144-147)
+            results.extend(ex.map(_cpu_item, items[i:i + 100]))
+    dt = time.perf_counter() - t0
+    return dict(value=round(sample / dt, 3), unit="frames/s", cores=workers, kind="port",
+                sample="%d frame pairs of the same workload, oracle/ C port under ProcessPoolExecutor(max_workers="
+                       "cpu_count//2=%d of %d cores), chunksize 1, batch_size 100" % (sample, workers, cores))
+
+
+# ---------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="frame pairs for the CPU baseline (0 = skip)")
+    ap.add_argument("--ssim-mode", default="gauss", choices=["gauss", "ffmpeg"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    wl = WORKLOADS[args.workload]
+    h, w, full = wl["h"], wl["w"], wl["full"]
+    B = args.batch or wl["batch"]
+
+    # CPU baseline first: its worker processes are forked before this process touches the GPU
+    cpu_line = None
+    if world == 1 and rank == 0 and args.cpu_sample != 0:
+        from rtvqa_amd import synth as _synth
+        sample = args.cpu_sample if args.cpu_sample > 0 else 32
+        r = _synth.s_natural(sample, h, w, seed=1234, stream_id=0, t0=0)
+        cpu_line = cpu_baseline(r, _synth.distort(r, t0=0), full, sample)
+        del r
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as td
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import rtvqa_amd
+    from rtvqa_amd import _native as N
+    from rtvqa_amd import synth
+    from rtvqa_amd.engine import DeviceBuffer, DeviceFrames, bgr_planes
+
+    eng = rtvqa_amd.Engine(local_rank)
+
+    # ---- synthetic streams, generated in chunks and made resident in HBM before timing
+    fbytes = h * w * 3
+    ref_buf, dist_buf = DeviceBuffer(eng, fbytes * (B + 1)), DeviceBuffer(eng, fbytes * (B + 1))
+    chunk = 32
+    for a in range(0, B + 1, chunk):
+        n = min(chunk, B + 1 - a)
+        r = synth.s_natural(n, h, w, seed=1234, stream_id=rank, t0=a)
+        d = synth.distort(r, t0=a)
+        N.check(eng.lib.vqa_copy_h2d(eng.ctx, ref_buf.ptr + a * fbytes, r.ctypes.data, r.nbytes), "h2d", eng.ctx)
+        N.check(eng.lib.vqa_copy_h2d(eng.ctx, dist_buf.ptr + a * fbytes, d.ctypes.data, d.nbytes), "h2d", eng.ctx)
+        eng.sync()
+    ref_all = DeviceFrames(ref_buf.ptr, B + 1, h, w, owner=ref_buf)
+    dist_all = DeviceFrames(dist_buf.ptr, B + 1, h, w, owner=dist_buf)
+    ref_b, dist_b, prev0 = ref_all.slice(1, B + 1), dist_all.slice(1, B + 1), dist_all.frame(0)
+
+    mask = N.M_ALL if full else (N.M_DCT | N.M_TEMPORAL_DCT)
+    params = eng.make_params(dct_mode=N.DCT_BLOCK8)
+    planes = bgr_planes(h, w)
+    smode = N.SSIM_GAUSS if args.ssim_mode == "gauss" else N.SSIM_FFMPEG
+
+    def step():
+        eng.quality_submit(ref_b, dist_b, planes, smode)
+        eng.complexity_submit(dist_b, prev0, mask, params)
+        q = eng.quality_wait()
+        c = eng.complexity_wait()
+        return q, c
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist_on:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile(True)
+    eng.profile_read(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        q, c = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read(reset=True)
+    eng.profile(False)
+
+    # ---- max over ranks, and the one scalar all-reduce the path has (pooled metrics)
+    if dist_on:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt = float(tmax.item())
+        pooled = torch.tensor([float(q["ssim"].mean()), float(c["dct_energy"].mean()), float(B)],
+                              dtype=torch.float64, device="cuda")
+        td.all_reduce(pooled, op=td.ReduceOp.SUM)  # RCCL over xGMI: 24 bytes, latency-bound
+    frames_total = B * args.steps * world
+    value = frames_total / dt
+
+    if rank == 0:
+        P = h * w
+        alg_bytes = {  # algorithmic HBM bytes per profiled launch group (SURVEY.md §8d x frames per launch)
+            "k_ssim_gauss": 2 * P * B, "k_ssim_ffmpeg": 2 * P * B, "k_dct8": 2 * P * B,
+            "k_bgr2gray_hist": 4 * P * (B + 1), "k_canny_nms": 2 * P * B, "k_block_sad": 2 * P * B,
+        }
+        kernels = {}
+        for name, (ms, cnt) in prof.items():
+            per = ms / cnt
+            ent = {"ms_per_launch": round(per, 4), "launches": cnt, "share_of_kernel_time": 0.0}
+            if name in alg_bytes:
+                gbs = alg_bytes[name] / (per * 1e-3) / 1e9
+                ent.update({"alg_bytes": alg_bytes[name], "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
+            kernels[name] = ent
+        tot = sum(ms for ms, _ in prof.values()) or 1.0
+        for name, (ms, _) in prof.items():
+            kernels[name]["share_of_kernel_time"] = round(ms / tot, 4)
+        dom = max((k for k in prof if k in alg_bytes), key=lambda k: prof[k][0])
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kernels[dom]["frac_hbm"], "traffic": None,
+                "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch; "
+                        "k_ssim_gauss is VALU-bound by construction (DESIGN.md §5.5)"}
+        line = {
+            "metric": "frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->f32 (SSE/bins/SAD exact int)",
+            "data": "synthetic (synth.s_natural v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
+                    % synth.GENERATOR_VERSION,
+            "config": {"workload": wl["name"], "id": args.workload, "frames_per_step_per_gpu": B,
+                       "resident": "HBM", "ssim_mode": args.ssim_mode, "parallelism": "1 stream/GPU x%d" % world},
+            "roofline": roof, "kernels": kernels,
+        }
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        td.barrier()
+        td.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,196 @@
+/*
+ * vqa.h — C ABI of the MI355X-native per-frame video complexity / quality engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of
+ * zaki699/Real-Time-Video-Quality-Analysis (reference @ 2024-10-16):
+ *
+ *   complexity_metrics.py:246-310  calculate_average_scene_complexity
+ *   complexity_metrics.py:128-148  process_in_batches        (the data-parallel map)
+ *   complexity_metrics.py:313-579  process_*_frame           (the per-frame kernels)
+ *   video_processing.py:270-297    run_ffmpeg_metrics        (PSNR + SSIM)
+ *
+ * The reference has no FFI of its own (it is Python over opencv_python and an
+ * ffmpeg subprocess); the entry points below are what a ctypes binding for that
+ * path binds (INTEGRATION.md shows the stub).  Plain pointers and sizes only —
+ * no torch / numpy types.  Every function returns VQA_OK (0) or a negative
+ * vqa_status; nothing throws; there is no global state besides the HIP runtime.
+ *
+ * Threading: one vqa_ctx per device per host thread.  A ctx owns one HIP stream,
+ * its scratch planes and a pinned result staging area; it is NOT thread-safe.
+ * Buffers handed to a *_submit call must stay alive and unmodified until the
+ * matching *_wait returns.
+ *
+ * There is NO CPU fallback: vqa_create fails with VQA_ERR_NO_DEVICE when no
+ * gfx950 device is visible.
+ */
+#ifndef VQA_H
+#define VQA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define VQA_API __attribute__((visibility("default")))
+#else
+#define VQA_API
+#endif
+
+#define VQA_ABI_VERSION 1
+
+typedef enum vqa_status {
+    VQA_OK = 0,
+    VQA_ERR_INVALID = -1,     /* bad argument (NULL, non-positive size, bad mask ...)   */
+    VQA_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range              */
+    VQA_ERR_HIP = -3,         /* a HIP runtime call failed (vqa_last_hip_error)         */
+    VQA_ERR_OOM = -4,         /* device or pinned allocation failed                     */
+    VQA_ERR_UNSUPPORTED = -5, /* valid request this build does not implement            */
+    VQA_ERR_STATE = -6        /* wait without submit, submit while one is pending ...   */
+} vqa_status;
+
+typedef struct vqa_ctx vqa_ctx;
+
+/* where a frame pointer handed to *_submit lives */
+typedef enum vqa_mem_kind {
+    VQA_MEM_HOST = 0,   /* pageable or pinned host memory: the engine copies H2D on its stream */
+    VQA_MEM_DEVICE = 1  /* device memory on the ctx's device (vqa_alloc_device, torch data_ptr) */
+} vqa_mem_kind;
+
+/* ---- metric selection (one bit per reference kernel) --------------------- */
+#define VQA_M_GRAY_HIST     (1u << 0) /* process_histogram_frame        complexity_metrics.py:392-416 */
+#define VQA_M_COLOR_HIST    (1u << 1) /* process_color_histogram_frame  complexity_metrics.py:418-475 */
+#define VQA_M_DCT           (1u << 2) /* process_dct_frame              complexity_metrics.py:346-364 */
+#define VQA_M_TEMPORAL_DCT  (1u << 3) /* process_temporal_dct_frame     complexity_metrics.py:543-579 */
+#define VQA_M_EDGE          (1u << 4) /* process_edge_frame             complexity_metrics.py:477-504 */
+#define VQA_M_MOTION        (1u << 5) /* process_frame_complexity       complexity_metrics.py:313-343
+                                         (block-SAD substitute for Farneback)         */
+#define VQA_M_ALL           0x3Fu
+
+/* dct_mode */
+#define VQA_DCT_AUTO   0 /* FULL when resize_w*resize_h <= 128*128, else BLOCK8            */
+#define VQA_DCT_BLOCK8 1 /* 8x8 block DCT-II (north_star).  Energy == full-frame energy     */
+#define VQA_DCT_FULL   2 /* one full-frame DCT-II, exactly what cv2.dct computes            */
+
+/* ssim_mode */
+#define VQA_SSIM_GAUSS  0 /* 11x11 Gaussian window, sigma 1.5 (north_star)                  */
+#define VQA_SSIM_FFMPEG 1 /* FFmpeg vf_ssim: integer 8x8 window, stride 4 (what the
+                             reference's subprocess really computes, video_processing.py:276) */
+
+typedef struct vqa_params {
+    int32_t resize_w, resize_h; /* cv2.resize target; 0 or == frame size -> native (copy)  */
+    int32_t canny_low, canny_high; /* cv2.Canny thresholds; reference uses 100, 200 (:503)  */
+    int32_t sad_range;          /* block-SAD search radius R, 0..7 (default 7)              */
+    int32_t dct_mode;           /* VQA_DCT_*                                                */
+    int32_t reserved[10];       /* must be zero                                             */
+} vqa_params;
+
+/* Per-frame results of the complexity kernels.  Integer fields are exact
+ * (bit-identical to the CPU reference); double fields carry float sums.    */
+typedef struct vqa_frame_metrics {
+    uint32_t hist_gray[256];     /* calcHist of gray(resize(frame))        (:404-412)       */
+    uint32_t hist_bgr[3][256];   /* calcHist of resize(frame) channels B,G,R (:430,455-457) */
+    uint64_t sum_gray2;          /* exact sum of squares of the DCT input plane (Parseval)  */
+    double   dct_energy;         /* sum(dct(resize(gray(frame)))**2)       (:358-364)       */
+    double   temporal_dct_l1;    /* sum|dct(prev) - dct(curr)|; 0 if no previous frame      */
+    uint64_t sad_sum;            /* sum over blocks of the winning SAD                      */
+    uint32_t sad_blocks;         /* number of 16x16 blocks measured; 0 if no previous frame */
+    uint32_t mv_d2_hist[129];    /* blocks per winning dx^2+dy^2                            */
+    uint32_t edge_count;         /* np.sum(cv2.Canny(gray,low,high) > 0)   (:503-504)       */
+    uint32_t edge_strong;        /* pixels above `high` that survive NMS                    */
+    uint32_t edge_weak;          /* NMS survivors in (low, high]                            */
+    uint32_t has_prev;           /* 1 if a previous frame was available                     */
+    uint32_t pad_;
+} vqa_frame_metrics;
+
+/* One 8-bit plane inside a frame buffer (planar YUV plane, or one channel of
+ * packed BGR with pixel_step = 3).                                          */
+typedef struct vqa_plane_desc {
+    int32_t width, height;
+    int64_t offset;      /* bytes from the start of the frame                 */
+    int64_t row_stride;  /* bytes between rows                                */
+    int32_t pixel_step;  /* bytes between horizontally adjacent samples       */
+    int32_t pad_;
+} vqa_plane_desc;
+
+typedef struct vqa_plane_metrics {
+    uint64_t sse;   /* sum (ref - dist)^2 over the plane — FFmpeg psnr's per-component sum */
+    double   ssim;  /* mean SSIM of the plane in the selected ssim_mode                     */
+} vqa_plane_metrics;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+VQA_API int vqa_abi_version(void);
+VQA_API const char *vqa_strerror(int status);
+VQA_API int vqa_device_count(int *count);
+VQA_API int vqa_create(int device, vqa_ctx **out);
+VQA_API int vqa_destroy(vqa_ctx *ctx);
+/* text of the last failing HIP call on this ctx ("" if none) */
+VQA_API const char *vqa_last_hip_error(const vqa_ctx *ctx);
+VQA_API void vqa_default_params(vqa_params *p);
+
+/* ---- memory --------------------------------------------------------------- */
+VQA_API int vqa_alloc_pinned(vqa_ctx *ctx, size_t bytes, void **out);
+VQA_API int vqa_free_pinned(vqa_ctx *ctx, void *p);
+VQA_API int vqa_alloc_device(vqa_ctx *ctx, size_t bytes, void **out);
+VQA_API int vqa_free_device(vqa_ctx *ctx, void *p);
+/* async on the ctx stream; host side should be pinned for true overlap */
+VQA_API int vqa_copy_h2d(vqa_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+VQA_API int vqa_copy_d2h(vqa_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+VQA_API int vqa_sync(vqa_ctx *ctx);
+/* the ctx's hipStream_t, as an opaque pointer (for event timing by the caller) */
+VQA_API void *vqa_stream(vqa_ctx *ctx);
+
+/* ---- complexity kernels (replaces process_in_batches over process_*_frame) - */
+/* frames: n packed BGR24 frames (what cv2.VideoCapture.read yields,
+ * complexity_metrics.py:100), frame i at frames + i*frame_stride, rows of
+ * 3*w bytes at row_stride.  prev0: the frame preceding frames[0] (same
+ * geometry, same mem_kind) or NULL; frame i's "previous" is frame i-1.
+ * Asynchronous: returns once the work is enqueued.                           */
+VQA_API int vqa_complexity_submit(vqa_ctx *ctx, const uint8_t *frames, const uint8_t *prev0, int mem_kind,
+                          int n, int h, int w, int64_t frame_stride, int64_t row_stride,
+                          uint32_t metric_mask, const vqa_params *params);
+/* blocks until the submitted batch is done, then fills out[0..n) */
+VQA_API int vqa_complexity_wait(vqa_ctx *ctx, vqa_frame_metrics *out, int n);
+
+/* ---- quality kernels (replaces run_ffmpeg_metrics' psnr + ssim filters) ---- */
+/* ref/dist: n frames each; every frame holds n_planes planes described by
+ * planes[].  out of vqa_quality_wait: n*n_planes entries, frame-major.        */
+VQA_API int vqa_quality_submit(vqa_ctx *ctx, const uint8_t *ref, const uint8_t *dist, int mem_kind, int n,
+                       int64_t ref_frame_stride, int64_t dist_frame_stride,
+                       const vqa_plane_desc *planes, int n_planes, int ssim_mode);
+VQA_API int vqa_quality_wait(vqa_ctx *ctx, vqa_plane_metrics *out, int n_entries);
+
+/* ---- per-kernel timing (HIP events on the ctx stream) ----------------------- */
+enum vqa_kernel_id {
+    VQA_K_GRAY_HIST = 0, /* BGR->gray + histograms, native resolution   */
+    VQA_K_RESIZE = 1,    /* cv2.resize gather + gray + histograms       */
+    VQA_K_DCT8 = 2,      /* 8x8 DCT energy + temporal L1                */
+    VQA_K_DCT_FULL = 3,  /* full-frame DCT (4 launches per batch)       */
+    VQA_K_CANNY_NMS = 4,
+    VQA_K_CANNY_HYST = 5,
+    VQA_K_SAD = 6,
+    VQA_K_SSIM_GAUSS = 7,
+    VQA_K_SSIM_FFMPEG = 8,
+    VQA_K_COUNT = 9
+};
+/* When enabled, every kernel launch made by a submit call is bracketed by a
+ * hipEvent pair recorded on the ctx stream; the elapsed times are accumulated
+ * per kernel id when the batch is waited for.                                 */
+VQA_API int vqa_profile_enable(vqa_ctx *ctx, int on);
+VQA_API int vqa_profile_read(vqa_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches, int reset);
+VQA_API const char *vqa_kernel_name(int kernel_id);
+
+/* ---- introspection for tests (device-side intermediates) ------------------ */
+/* Copies intermediate planes of the LAST complexity batch to host memory:
+ * which = 0: DCT input plane  (resize(gray(frame)))   [n][ph][pw]
+ * which = 1: hist/edge plane  (gray(resize(frame)))   [n][ph][pw]
+ * which = 2: Canny edge map, 0/255                    [n][ph][pw]
+ * which = 3: full-resolution gray (motion input)      [n][h][w]              */
+VQA_API int vqa_debug_read_plane(vqa_ctx *ctx, int which, int frame, uint8_t *dst, int dst_h, int dst_w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_H */

@@ -1,0 +1,390 @@
+"""Host-side mirror of the reference's complexity interface, backed by the HIP engine.
+
+Same names, argument meaning, return order and error behaviour as
+/root/reference/complexity_metrics.py for the hot path:
+
+    calculate_average_scene_complexity   (:246-310)
+    process_in_batches                   (:128-148)
+    process_frame_complexity / process_dct_frame / process_histogram_frame /
+    process_color_histogram_frame / process_edge_frame /
+    process_temporal_dct_frame           (:313-579)
+    smooth_data, normalize, process_frame_interval_for_parallel,
+    calculate_scene_complexity_score     (:114-242)
+
+Differences that are deliberate:
+  * frames come from arrays / .npy files / iterables, not cv2.VideoCapture (decode
+    is out of scope; no codec exists in the target image);
+  * the dispatcher does not fork (a HIP context does not survive fork): a batch of
+    frames is one kernel launch instead of one pickled frame per pool task;
+  * motion is block-SAD, not Farneback (BASELINE.json north_star);
+  * ORB keypoint counting is out of scope: its tuple slot holds NaN.
+No metric is ever computed on the CPU here; without the HIP library this module
+raises on first use.
+"""
+import functools
+import logging
+import os
+
+import numpy as np
+
+from . import _native as N
+from .engine import DeviceFrames, Engine
+from .pooling import smooth_data as _ewm
+
+logger = logging.getLogger(__name__)
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """One Engine per (process, device).  Default device: LOCAL_RANK, else 0."""
+    if device is None:
+        device = int(os.environ.get("VQA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]
+
+
+# ---------------------------------------------------------------------------
+# frame sources (replaces validate_video_path / read_frame_pairs / extract_frame_timestamps)
+# ---------------------------------------------------------------------------
+def validate_video_path(input_path):
+    """complexity_metrics.py:25-35 with this build's container formats."""
+    if not isinstance(input_path, str):
+        raise ValueError("Invalid input path. Please provide a valid file path.")
+    if input_path.endswith((".npy",)):
+        return "video"
+    raise ValueError("Unsupported file type. Please provide a .npy frame stack [N,H,W,3] (uint8, BGR).")
+
+
+def _open_frames(video):
+    """-> array-like [N,H,W,3] uint8 (np.ndarray, memmap or DeviceFrames)."""
+    if isinstance(video, DeviceFrames):
+        return video
+    if isinstance(video, str):
+        validate_video_path(video)
+        if not os.path.isfile(video):
+            logger.error("Error opening video file: %s", video)
+            return np.zeros((0, 1, 1, 3), np.uint8)
+        return np.load(video, mmap_mode="r")
+    arr = video if isinstance(video, np.ndarray) else np.stack([np.asarray(f) for f in video])
+    if arr.ndim != 4 or arr.shape[3] != 3 or arr.dtype != np.uint8:
+        raise ValueError("frames must be uint8 [N,H,W,3] packed BGR")
+    return arr
+
+
+def _num_frames(fr):
+    return fr.n if isinstance(fr, DeviceFrames) else fr.shape[0]
+
+
+def selected_indices(num_frames, frame_interval):
+    """0-based indices read_frame_pairs keeps: 1-based count % interval == 0 (:103-104)."""
+    return np.arange(frame_interval - 1, num_frames, frame_interval)
+
+
+def read_frame_pairs(video_path, frame_interval=10):
+    """complexity_metrics.py:76-111 — list of (current, previous) selected frames."""
+    fr = _open_frames(video_path)
+    if isinstance(fr, DeviceFrames):
+        raise TypeError("read_frame_pairs returns host frames; pass host frames")
+    idx = selected_indices(fr.shape[0], frame_interval)
+    return [(np.asarray(fr[idx[j]]), np.asarray(fr[idx[j - 1]])) for j in range(1, len(idx))]
+
+
+def extract_frame_timestamps(video_path, frame_interval=10, fps=30.0):
+    """complexity_metrics.py:38-73 for a constant-rate source: timestamps (ms) of the
+    frames whose 0-based index % interval == 0 (:65; note the different phase from
+    read_frame_pairs).  OpenCV's CAP_PROP_POS_MSEC after reading frame i is i*1000/fps."""
+    fr = _open_frames(video_path)
+    n = _num_frames(fr)
+    return [float(i) * 1000.0 / fps for i in range(0, n, frame_interval)]
+
+
+# ---------------------------------------------------------------------------
+# pooling
+# ---------------------------------------------------------------------------
+def smooth_data(data, alpha=0.8):
+    """complexity_metrics.py:114-125 (CPU branch): pandas ewm(alpha).mean() as a NumPy array."""
+    return _ewm(data, alpha)
+
+
+def normalize(value, min_value, max_value):
+    """complexity_metrics.py:167-169."""
+    return (value - min_value) / (max_value - min_value) if max_value > min_value else 0
+
+
+def process_frame_interval_for_parallel(timestamps):
+    """complexity_metrics.py:150-165 — frame rate between two timestamps (ms)."""
+    prev_timestamp, curr_timestamp = timestamps
+    frame_interval = (curr_timestamp - prev_timestamp) / 1000.0
+    if frame_interval > 0:
+        return 1.0 / frame_interval
+    return 0.0
+
+
+# ---------------------------------------------------------------------------
+# counts -> reference scalars (the float tails the reference runs in NumPy)
+# ---------------------------------------------------------------------------
+def _gray_entropy(counts):
+    hist = counts.astype(np.float32).reshape(256, 1)      # calcHist returns float32 (256,1)
+    hist = hist / hist.sum()                              # :413
+    return -np.sum(hist[hist > 0] * np.log2(hist[hist > 0]))  # :414
+
+
+def _color_entropy(counts_bgr):
+    hist_b, hist_g, hist_r = (counts_bgr[c].astype(np.float32).reshape(256, 1) for c in range(3))
+    sb, sg, sr = hist_b.sum(), hist_g.sum(), hist_r.sum()
+    if sb == 0 or sg == 0 or sr == 0:                     # :464-465
+        return float("nan")
+    hist_b, hist_g, hist_r = hist_b / sb, hist_g / sg, hist_r / sr
+    return -(np.sum(hist_b * np.log2(hist_b + 1e-8)) + np.sum(hist_g * np.log2(hist_g + 1e-8)) +
+             np.sum(hist_r * np.log2(hist_r + 1e-8)))     # :471-473
+
+
+_SQRT_K = np.sqrt(np.arange(129, dtype=np.float64))
+
+
+def _motion_magnitude(rec):
+    nb = int(rec["sad_blocks"])
+    if nb == 0:
+        return np.float32(0.0)
+    return np.float32(np.dot(rec["mv_d2_hist"].astype(np.float64), _SQRT_K) / nb)
+
+
+def _scalar(kind, rec):
+    if kind == "dct":
+        return np.float32(rec["dct_energy"])
+    if kind == "temporal":
+        return np.float32(rec["temporal_dct_l1"])
+    if kind == "hist":
+        return _gray_entropy(rec["hist_gray"])
+    if kind == "color":
+        return _color_entropy(rec["hist_bgr"])
+    if kind == "edge":
+        return np.int64(rec["edge_count"])
+    if kind == "motion":
+        return _motion_magnitude(rec)
+    raise KeyError(kind)
+
+
+_MASK = {"dct": N.M_DCT, "temporal": N.M_TEMPORAL_DCT, "hist": N.M_GRAY_HIST, "color": N.M_COLOR_HIST,
+         "edge": N.M_EDGE, "motion": N.M_MOTION}
+
+
+# ---------------------------------------------------------------------------
+# per-frame callables (same signatures as the reference's process_* functions)
+# ---------------------------------------------------------------------------
+def _one(kind, frame, resize_width, resize_height):
+    frame = np.asarray(frame)
+    if frame.ndim == 2:  # gray input: B=G=R=v makes cvtColor the identity (3735+19235+9798 = 2^15)
+        frame = np.repeat(frame[..., None], 3, axis=2)
+    eng = get_engine()
+    rec = eng.complexity(frame[None], mask=_MASK[kind], resize=(resize_width, resize_height))
+    return _scalar(kind, rec[0])
+
+
+def process_dct_frame(frame, resize_width, resize_height):
+    """complexity_metrics.py:346-364 — sum of squared DCT coefficients of resize(gray(frame))."""
+    return _one("dct", frame, resize_width, resize_height)
+
+
+def process_histogram_frame(frame, resize_width, resize_height):
+    """complexity_metrics.py:392-416 — Shannon entropy of the gray histogram."""
+    return _one("hist", frame, resize_width, resize_height)
+
+
+def process_color_histogram_frame(frame, resize_width, resize_height):
+    """complexity_metrics.py:418-475 — summed entropy of the B, G, R histograms."""
+    return _one("color", frame, resize_width, resize_height)
+
+
+def process_edge_frame(frame, resize_width, resize_height):
+    """complexity_metrics.py:477-504 — number of Canny(100,200) edge pixels."""
+    return _one("edge", frame, resize_width, resize_height)
+
+
+def process_frame_complexity(frame_pair):
+    """complexity_metrics.py:313-343 — motion between (current, previous); block-SAD mean |mv|."""
+    frame, prev_frame = frame_pair
+    if frame is None or prev_frame is None:
+        return 0.0
+    eng = get_engine()
+    rec = eng.complexity(np.asarray(frame)[None], prev0=np.asarray(prev_frame), mask=N.M_MOTION)
+    return _scalar("motion", rec[0])
+
+
+def process_temporal_dct_frame(prev_gray_frame, curr_gray_frame, resize_width, resize_height):
+    """complexity_metrics.py:543-579 — sum |dct(prev) - dct(curr)| of two gray frames."""
+    prev3 = np.repeat(np.asarray(prev_gray_frame)[..., None], 3, axis=2)
+    curr3 = np.repeat(np.asarray(curr_gray_frame)[..., None], 3, axis=2)
+    eng = get_engine()
+    rec = eng.complexity(curr3[None], prev0=prev3, mask=N.M_TEMPORAL_DCT, resize=(resize_width, resize_height))
+    return _scalar("temporal", rec[0])
+
+
+def process_orb_frame_for_parallel(frame):
+    """complexity_metrics.py:367-389 — OUT OF SCOPE (not named by north_star)."""
+    raise NotImplementedError("ORB keypoint counting is outside this build's hot-path scope")
+
+
+_KNOWN = {process_dct_frame: "dct", process_histogram_frame: "hist", process_color_histogram_frame: "color",
+          process_edge_frame: "edge", process_frame_complexity: "motion"}
+
+
+def _unwrap(func, kwargs):
+    """Peel functools.partial layers; returns (base function, merged keyword arguments)."""
+    kw = dict(kwargs)
+    args = ()
+    while isinstance(func, functools.partial):
+        merged = dict(func.keywords or {})
+        merged.update(kw)
+        kw = merged
+        args = tuple(func.args) + args
+        func = func.func
+    return func, args, kw
+
+
+def process_in_batches(frames, process_func, num_workers, batch_size=100, **kwargs):
+    """complexity_metrics.py:128-148 — ordered map of process_func over frames in chunks.
+
+    When process_func is one of this module's kernels the whole chunk becomes ONE
+    batched launch on the device (num_workers is accepted and ignored: there is no
+    process pool to size).  Any other callable is mapped in-process, in order."""
+    base, pargs, kw = _unwrap(process_func, kwargs)
+    kind = _KNOWN.get(base)
+    results = []
+    if kind is None or pargs:
+        call = functools.partial(process_func, **kwargs)
+        for i in range(0, len(frames), batch_size):
+            results.extend(call(item) for item in frames[i:i + batch_size])
+        return results
+    eng = get_engine()
+    for i in range(0, len(frames), batch_size):
+        batch = frames[i:i + batch_size]
+        if kind == "motion":
+            results.extend(_motion_batch(eng, batch))
+            continue
+        resize = (kw["resize_width"], kw["resize_height"])
+        arr = np.stack([np.asarray(f) for f in batch])
+        rec = eng.complexity(arr, mask=_MASK[kind], resize=resize)
+        results.extend(_scalar(kind, r) for r in rec)
+    return results
+
+
+def _motion_batch(eng, pairs):
+    out = [None] * len(pairs)
+    live = [j for j, p in enumerate(pairs) if p[0] is not None and p[1] is not None]
+    for j in range(len(pairs)):
+        if j not in live:
+            out[j] = 0.0  # :324-325
+    if not live:
+        return out
+    chained = all(pairs[live[k]][1] is pairs[live[k - 1]][0] for k in range(1, len(live))) and \
+        live == list(range(live[0], live[0] + len(live)))
+    if chained:
+        arr = np.stack([np.asarray(pairs[j][0]) for j in live])
+        rec = eng.complexity(arr, prev0=np.asarray(pairs[live[0]][1]), mask=N.M_MOTION)
+        for k, j in enumerate(live):
+            out[j] = _scalar("motion", rec[k])
+    else:
+        # arbitrary pairs: interleave (prev, curr) and keep every second result
+        arr = np.stack([np.asarray(pairs[j][s]) for j in live for s in (1, 0)])
+        rec = eng.complexity(arr, mask=N.M_MOTION)
+        for k, j in enumerate(live):
+            out[j] = _scalar("motion", rec[2 * k + 1])
+    return out
+
+
+# ---------------------------------------------------------------------------
+# the aggregator
+# ---------------------------------------------------------------------------
+def complexity_series(video, resize_width, resize_height, frame_interval=10, batch_size=100, engine=None,
+                      dct_mode=N.DCT_AUTO, mask=N.M_ALL):
+    """Per-frame series for the frames the reference measures, from ONE fused pass.
+
+    Returns dict kind -> list, each in the reference's sample order:
+      motion/dct/hist/edge/color : T-1 samples (selected frames S_1..S_{T-1}; :268-290)
+      temporal                   : T-2 samples (S_1->S_2 ... ; :533-537)
+    """
+    fr = _open_frames(video)
+    eng = engine or get_engine()
+    idx = selected_indices(_num_frames(fr), frame_interval)
+    out = {k: [] for k in ("motion", "dct", "hist", "edge", "color", "temporal")}
+    if len(idx) < 2:
+        return out
+    params = eng.make_params(resize=(resize_width, resize_height), dct_mode=dct_mode)
+    sel = idx[1:]
+    prev_i = idx[0]
+    for a in range(0, len(sel), batch_size):
+        chunk = sel[a:a + batch_size]
+        if isinstance(fr, DeviceFrames):
+            if frame_interval == 1:
+                batch = fr.slice(int(chunk[0]), int(chunk[-1]) + 1)
+            else:
+                raise NotImplementedError("device-resident sources need frame_interval == 1")
+            prev0 = fr.frame(int(prev_i))
+        else:
+            batch = np.ascontiguousarray(fr[chunk]) if frame_interval != 1 else np.asarray(fr[chunk[0]:chunk[-1] + 1])
+            prev0 = np.asarray(fr[prev_i])
+        rec = eng.complexity(batch, prev0=prev0, mask=mask, params=params)
+        for j, r in enumerate(rec):
+            for kind in ("motion", "dct", "hist", "edge", "color"):
+                if mask & _MASK[kind]:
+                    out[kind].append(_scalar(kind, r))
+            # the reference's first pair only primes prev_gray_frame (:533-537)
+            if (mask & N.M_TEMPORAL_DCT) and not (a == 0 and j == 0):
+                out["temporal"].append(_scalar("temporal", r))
+        prev_i = chunk[-1]
+    return out
+
+
+def calculate_temporal_dct(video_path, resize_width, resize_height, frame_interval=10, smoothing_factor=0.8):
+    """complexity_metrics.py:506-541."""
+    s = complexity_series(video_path, resize_width, resize_height, frame_interval, mask=N.M_TEMPORAL_DCT)["temporal"]
+    sm = smooth_data(s, smoothing_factor)
+    return np.mean(sm) if len(sm) > 0 else 0.0
+
+
+def calculate_average_scene_complexity(video_path, resize_width, resize_height, frame_interval=10,
+                                       smoothing_factor=0.8, num_workers=None, batch_size=100, fps=30.0):
+    """complexity_metrics.py:246-310.  Returns the 8-tuple in the reference's order (:301-310):
+    (motion, dct, histogram, edge, orb, colour_histogram, temporal_dct, framerate_variation).
+    `video_path` may be a .npy path, an ndarray [N,H,W,3] or DeviceFrames.  orb is NaN (out of scope)."""
+    s = complexity_series(video_path, resize_width, resize_height, frame_interval, batch_size)
+
+    def pooled(x):
+        with np.errstate(invalid="ignore"), _quiet_empty_mean():
+            return np.mean(smooth_data(x, smoothing_factor))
+
+    temporal = smooth_data(s["temporal"], smoothing_factor)
+    temporal_dct_complexity = np.mean(temporal) if len(temporal) > 0 else 0.0
+    frame_timestamps = extract_frame_timestamps(video_path, frame_interval, fps)
+    timestamp_pairs = list(zip(frame_timestamps[:-1], frame_timestamps[1:]))
+    framerate_variation = process_in_batches(timestamp_pairs, process_frame_interval_for_parallel, num_workers, batch_size)
+    return (pooled(s["motion"]), pooled(s["dct"]), pooled(s["hist"]), pooled(s["edge"]), float("nan"),
+            pooled(s["color"]), temporal_dct_complexity, pooled(framerate_variation))
+
+
+class _quiet_empty_mean:
+    """np.mean([]) warns and returns NaN — the reference's behaviour for an unopenable video (:56-58)."""
+
+    def __enter__(self):
+        import warnings
+        self._cm = warnings.catch_warnings()
+        self._cm.__enter__()
+        warnings.simplefilter("ignore", RuntimeWarning)
+
+    def __exit__(self, *a):
+        return self._cm.__exit__(*a)
+
+
+def calculate_scene_complexity_score(encoded_video, resize_width, resize_height, frame_interval=10,
+                                     smoothing_factor=0.8, num_workers=None, batch_size=100):
+    """complexity_metrics.py:171-242 — min/max normalisation (:197-206) and weights (:219-228)."""
+    (motion, dct, hist, edge, orb, color, temporal, fpsvar) = calculate_average_scene_complexity(
+        encoded_video, resize_width, resize_height, frame_interval=frame_interval,
+        smoothing_factor=smoothing_factor, num_workers=None, batch_size=batch_size)
+    table = (  # (value, min, max, weight)
+        (motion, 0.0, 10.0, 0.25), (dct, 1e6, 5e7, 0.15), (temporal, 0.0, 1e7, 0.15), (hist, 0.0, 8.0, 0.10),
+        (edge, 0.0, 1.0, 0.10), (orb, 0.0, 5000, 0.10), (color, 0.0, 8.0, 0.10), (fpsvar, 0.0, 2.0, 0.05))
+    return sum(normalize(v, lo, hi) * wt for v, lo, hi, wt in table)

@@ -1,0 +1,669 @@
+// vqa_capi.hip — the C ABI declared in include/vqa.h: context, memory, and the
+// orchestration of the gfx950 kernels for one batch of frames.
+//
+// No CPU fallback lives here: every metric is produced by a HIP kernel or the
+// call fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "vqa_kernels.hpp"
+
+using namespace vqa;
+
+namespace {
+
+struct dbuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct resize_tabs {
+    int32_t *xofs = nullptr, *xa = nullptr, *yofs = nullptr, *yb = nullptr;
+    int mode = 0;
+};
+
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+} // namespace
+
+struct vqa_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string last_err;
+
+    // device scratch (grow-only)
+    dbuf gray_full, planeA, planeB, state, res_dev, partials, tile_flags, dirty0, dirty1, again_dev;
+    dbuf stage_frames, stage_prev, dct_scratch, dct_pe, dct_pt;
+    dbuf qres_dev, qpartials, qstage_ref, qstage_dist;
+    // pinned host staging
+    void *res_host = nullptr; size_t res_host_cap = 0;
+    void *qres_host = nullptr; size_t qres_host_cap = 0;
+    uint32_t *again_host = nullptr;
+
+    std::map<std::tuple<int, int, int, int>, resize_tabs> tabs;
+    std::map<int, float *> dct_mats;
+
+    // pending work
+    int pend_c = 0, pend_q = 0;
+    bool pend_c_prev0 = false;
+    // geometry of the last complexity batch (debug reads)
+    int last_n = 0, last_h = 0, last_w = 0, last_ph = 0, last_pw = 0, last_pp = 0, last_gp = 0;
+    bool last_resized = false, last_has_full = false, last_has_state = false, last_has_planes = false;
+    uint32_t canny_rounds = 0;
+
+    // per-kernel timing
+    bool prof_on = false;
+    std::vector<hipEvent_t> ev_pool;                   // recycled events
+    std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> ev_open; // (kernel id, start, stop) not yet read
+    double prof_ms[VQA_K_COUNT] = {0};
+    int64_t prof_n[VQA_K_COUNT] = {0};
+};
+
+namespace {
+// RAII bracket: records start now and stop at scope exit when profiling is on.
+struct prof_scope {
+    vqa_ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t get(vqa_ctx *c)
+    {
+        if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    prof_scope(vqa_ctx *c_, int id_) : c(c_), id(id_)
+    {
+        if (!c->prof_on) return;
+        a = get(c); b = get(c);
+        if (a && b) (void)hipEventRecord(a, c->stream);
+    }
+    ~prof_scope()
+    {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->ev_open.emplace_back(id, a, b);
+    }
+};
+
+// after the stream has been synchronised: fold the open event pairs into the totals
+void prof_collect(vqa_ctx *c)
+{
+    for (auto &t : c->ev_open) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, std::get<1>(t), std::get<2>(t)) == hipSuccess) {
+            c->prof_ms[std::get<0>(t)] += ms;
+            c->prof_n[std::get<0>(t)] += 1;
+        }
+        c->ev_pool.push_back(std::get<1>(t));
+        c->ev_pool.push_back(std::get<2>(t));
+    }
+    c->ev_open.clear();
+}
+} // namespace
+
+#define HIPCHK(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            char b_[512];                                                                                  \
+            snprintf(b_, sizeof b_, "%s -> %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->last_err = b_;                                                                          \
+            return e_ == hipErrorOutOfMemory ? VQA_ERR_OOM : VQA_ERR_HIP;                                  \
+        }                                                                                                  \
+    } while (0)
+
+static int ensure(vqa_ctx *c, dbuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return VQA_OK;
+    // contents are scratch; a pending async user would be on our own stream
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return VQA_OK;
+}
+
+static int ensure_pinned(vqa_ctx *c, void *&p, size_t &cap, size_t bytes)
+{
+    if (bytes <= cap) return VQA_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (p) HIPCHK(c, hipHostFree(p));
+    p = nullptr; cap = 0;
+    HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return VQA_OK;
+}
+
+// OpenCV resize.cpp coefficient tables for INTER_LINEAR on 8-bit data (see
+// DESIGN.md §4.2; restated independently of the oracle's copy).
+static void build_axis(int ssize, int dsize, bool is_x, std::vector<int32_t> &ofs, std::vector<int32_t> &coef)
+{
+    ofs.resize(dsize);
+    coef.resize(2 * (size_t)dsize);
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    for (int d = 0; d < dsize; d++) {
+        float fr = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(fr);
+        fr -= (float)s;
+        if (is_x) {
+            if (s < 0) { fr = 0.f; s = 0; }
+            if (s >= ssize - 1) { fr = 0.f; s = ssize - 1; }
+        }
+        ofs[d] = s;
+        long a0 = lrintf((1.f - fr) * 2048.f), a1 = lrintf(fr * 2048.f);
+        a0 = a0 < -32768 ? -32768 : (a0 > 32767 ? 32767 : a0);
+        a1 = a1 < -32768 ? -32768 : (a1 > 32767 ? 32767 : a1);
+        coef[2 * (size_t)d] = (int32_t)a0;
+        coef[2 * (size_t)d + 1] = (int32_t)a1;
+    }
+}
+
+static int get_tabs(vqa_ctx *c, int h, int w, int rh, int rw, resize_tabs &out)
+{
+    auto key = std::make_tuple(h, w, rh, rw);
+    auto it = c->tabs.find(key);
+    if (it != c->tabs.end()) { out = it->second; return VQA_OK; }
+    resize_tabs t;
+    t.mode = (w == 2 * rw && h == 2 * rh) ? 1 : 0;
+    std::vector<int32_t> xo, xa, yo, yb;
+    build_axis(w, rw, true, xo, xa);
+    build_axis(h, rh, false, yo, yb);
+    HIPCHK(c, hipMalloc((void **)&t.xofs, sizeof(int32_t) * rw));
+    HIPCHK(c, hipMalloc((void **)&t.xa, sizeof(int32_t) * 2 * rw));
+    HIPCHK(c, hipMalloc((void **)&t.yofs, sizeof(int32_t) * rh));
+    HIPCHK(c, hipMalloc((void **)&t.yb, sizeof(int32_t) * 2 * rh));
+    HIPCHK(c, hipMemcpy(t.xofs, xo.data(), sizeof(int32_t) * rw, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(t.xa, xa.data(), sizeof(int32_t) * 2 * rw, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(t.yofs, yo.data(), sizeof(int32_t) * rh, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(t.yb, yb.data(), sizeof(int32_t) * 2 * rh, hipMemcpyHostToDevice));
+    c->tabs[key] = t;
+    out = t;
+    return VQA_OK;
+}
+
+// orthonormal DCT-II matrix C[k][i] = s_k cos(pi (2i+1) k / 2N)  (what cv2.dct applies)
+static int get_dct_matrix(vqa_ctx *c, int n, float **out)
+{
+    auto it = c->dct_mats.find(n);
+    if (it != c->dct_mats.end()) { *out = it->second; return VQA_OK; }
+    std::vector<float> m((size_t)n * n);
+    for (int k = 0; k < n; k++) {
+        const double s = k == 0 ? std::sqrt(1.0 / n) : std::sqrt(2.0 / n);
+        for (int i = 0; i < n; i++) m[(size_t)k * n + i] = (float)(s * std::cos(M_PI * (2.0 * i + 1.0) * k / (2.0 * n)));
+    }
+    float *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, sizeof(float) * m.size()));
+    HIPCHK(c, hipMemcpy(d, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice));
+    c->dct_mats[n] = d;
+    *out = d;
+    return VQA_OK;
+}
+
+extern "C" {
+
+int vqa_abi_version(void) { return VQA_ABI_VERSION; }
+
+const char *vqa_strerror(int s)
+{
+    switch (s) {
+    case VQA_OK: return "ok";
+    case VQA_ERR_INVALID: return "invalid argument";
+    case VQA_ERR_NO_DEVICE: return "no HIP device (this engine has no CPU fallback)";
+    case VQA_ERR_HIP: return "HIP runtime error";
+    case VQA_ERR_OOM: return "out of memory";
+    case VQA_ERR_UNSUPPORTED: return "unsupported request";
+    case VQA_ERR_STATE: return "call sequence error";
+    default: return "unknown status";
+    }
+}
+
+int vqa_device_count(int *count)
+{
+    if (!count) return VQA_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return VQA_ERR_NO_DEVICE; }
+    *count = n;
+    return VQA_OK;
+}
+
+void vqa_default_params(vqa_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->canny_low = 100;
+    p->canny_high = 200;
+    p->sad_range = 7;
+    p->dct_mode = VQA_DCT_AUTO;
+}
+
+int vqa_create(int device, vqa_ctx **out)
+{
+    if (!out) return VQA_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return VQA_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return VQA_ERR_NO_DEVICE;
+    vqa_ctx *c = new (std::nothrow) vqa_ctx();
+    if (!c) return VQA_ERR_OOM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&c->again_host, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return VQA_ERR_HIP;
+    }
+    *out = c;
+    return VQA_OK;
+}
+
+int vqa_destroy(vqa_ctx *c)
+{
+    if (!c) return VQA_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    dbuf *bufs[] = {&c->gray_full, &c->planeA, &c->planeB, &c->state, &c->res_dev, &c->partials, &c->tile_flags,
+                    &c->dirty0, &c->dirty1, &c->again_dev, &c->stage_frames, &c->stage_prev, &c->dct_scratch,
+                    &c->dct_pe, &c->dct_pt, &c->qres_dev, &c->qpartials, &c->qstage_ref, &c->qstage_dist};
+    for (dbuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto &kv : c->tabs) {
+        (void)hipFree(kv.second.xofs); (void)hipFree(kv.second.xa); (void)hipFree(kv.second.yofs); (void)hipFree(kv.second.yb);
+    }
+    for (auto &kv : c->dct_mats) (void)hipFree(kv.second);
+    for (auto &t : c->ev_open) { (void)hipEventDestroy(std::get<1>(t)); (void)hipEventDestroy(std::get<2>(t)); }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->res_host) (void)hipHostFree(c->res_host);
+    if (c->qres_host) (void)hipHostFree(c->qres_host);
+    if (c->again_host) (void)hipHostFree(c->again_host);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VQA_OK;
+}
+
+const char *vqa_last_hip_error(const vqa_ctx *c) { return c ? c->last_err.c_str() : ""; }
+
+int vqa_alloc_pinned(vqa_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || !bytes) return VQA_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return VQA_OK;
+}
+int vqa_free_pinned(vqa_ctx *c, void *p)
+{
+    if (!c || !p) return VQA_ERR_INVALID;
+    HIPCHK(c, hipHostFree(p));
+    return VQA_OK;
+}
+int vqa_alloc_device(vqa_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || !bytes) return VQA_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(out, bytes));
+    return VQA_OK;
+}
+int vqa_free_device(vqa_ctx *c, void *p)
+{
+    if (!c || !p) return VQA_ERR_INVALID;
+    HIPCHK(c, hipFree(p));
+    return VQA_OK;
+}
+int vqa_copy_h2d(vqa_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return VQA_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return VQA_OK;
+}
+int vqa_copy_d2h(vqa_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return VQA_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return VQA_OK;
+}
+int vqa_sync(vqa_ctx *c)
+{
+    if (!c) return VQA_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VQA_OK;
+}
+void *vqa_stream(vqa_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---------------------------------------------------------------------------
+int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev0, int mem_kind, int n, int h, int w,
+                          int64_t frame_stride, int64_t row_stride, uint32_t mask, const vqa_params *params)
+{
+    if (!c || !frames || n <= 0 || h <= 0 || w <= 0) return VQA_ERR_INVALID;
+    if (mem_kind != VQA_MEM_HOST && mem_kind != VQA_MEM_DEVICE) return VQA_ERR_INVALID;
+    if (!mask || (mask & ~VQA_M_ALL)) return VQA_ERR_INVALID;
+    if (row_stride < (int64_t)3 * w || frame_stride < row_stride * h) return VQA_ERR_INVALID;
+    if (c->pend_c) return VQA_ERR_STATE;
+    vqa_params P;
+    if (params) P = *params; else vqa_default_params(&P);
+    for (int i = 0; i < 10; i++)
+        if (P.reserved[i]) return VQA_ERR_INVALID;
+    if (P.sad_range < 0 || P.sad_range > 7) return VQA_ERR_INVALID;
+    if (P.resize_w < 0 || P.resize_h < 0 || ((P.resize_w == 0) != (P.resize_h == 0))) return VQA_ERR_INVALID;
+    if (P.dct_mode < VQA_DCT_AUTO || P.dct_mode > VQA_DCT_FULL) return VQA_ERR_INVALID;
+    if ((int64_t)h * w > (1ll << 28)) return VQA_ERR_UNSUPPORTED;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+
+    const int rw = P.resize_w ? P.resize_w : w, rh = P.resize_h ? P.resize_h : h;
+    const bool resized = !(rw == w && rh == h);
+    const int ph = rh, pw = rw;
+    const int pp = align_up(pw, 64), gp = align_up(w, 64);
+    const bool want_gh = mask & VQA_M_GRAY_HIST, want_ch = mask & VQA_M_COLOR_HIST, want_dct = mask & VQA_M_DCT;
+    const bool want_t = mask & VQA_M_TEMPORAL_DCT, want_e = mask & VQA_M_EDGE, want_m = mask & VQA_M_MOTION;
+    const bool has_prev0 = prev0 != nullptr;
+
+    // ---- bring frames to the device if they are on the host
+    const uint8_t *dframes = frames, *dprev = prev0;
+    if (mem_kind == VQA_MEM_HOST) {
+        const size_t span = (size_t)(n - 1) * frame_stride + (size_t)h * row_stride;
+        int rc = ensure(c, c->stage_frames, span);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->stage_frames.p, frames, span, hipMemcpyHostToDevice, st));
+        dframes = (const uint8_t *)c->stage_frames.p;
+        if (has_prev0) {
+            rc = ensure(c, c->stage_prev, (size_t)h * row_stride);
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->stage_prev.p, prev0, (size_t)h * row_stride, hipMemcpyHostToDevice, st));
+            dprev = (const uint8_t *)c->stage_prev.p;
+        }
+    }
+
+    int rc = ensure(c, c->res_dev, sizeof(vqa_frame_metrics) * (size_t)n);
+    if (rc) return rc;
+    rc = ensure_pinned(c, c->res_host, c->res_host_cap, sizeof(vqa_frame_metrics) * (size_t)n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->res_dev.p, 0, sizeof(vqa_frame_metrics) * (size_t)n, st));
+    vqa_frame_metrics *res = (vqa_frame_metrics *)c->res_dev.p;
+
+    // ---- planes
+    const bool need_full = !resized || want_m;
+    const bool need_planes = resized && (want_gh || want_ch || want_dct || want_t || want_e);
+    const int64_t full_stride = (int64_t)h * gp, plane_stride = (int64_t)ph * pp;
+    uint8_t *gfull = nullptr, *pA = nullptr, *pB = nullptr;
+    if (need_full) {
+        rc = ensure(c, c->gray_full, (size_t)full_stride * (n + 1));
+        if (rc) return rc;
+        gfull = (uint8_t *)c->gray_full.p;
+        const bool prev_needed = has_prev0 && (want_m || (!resized && want_t));
+        prof_scope ps_(c, VQA_K_GRAY_HIST);
+        if (prev_needed)
+            launch_bgr2gray_hist(st, dprev, 1, h, w, frame_stride, row_stride, gfull, gp, full_stride, nullptr, false,
+                                 false, false);
+        launch_bgr2gray_hist(st, dframes, n, h, w, frame_stride, row_stride, gfull + full_stride, gp, full_stride, res,
+                             !resized && want_gh, !resized && want_ch, !resized && want_dct);
+    }
+    if (need_planes) {
+        resize_tabs T;
+        rc = get_tabs(c, h, w, rh, rw, T);
+        if (rc) return rc;
+        rc = ensure(c, c->planeA, (size_t)plane_stride * (n + 1));
+        if (rc) return rc;
+        rc = ensure(c, c->planeB, (size_t)plane_stride * n);
+        if (rc) return rc;
+        pA = (uint8_t *)c->planeA.p;
+        pB = (uint8_t *)c->planeB.p;
+        prof_scope ps_(c, VQA_K_RESIZE);
+        if (has_prev0 && want_t)
+            launch_resize_planes(st, dprev, 1, h, w, frame_stride, row_stride, rw, rh, T.xofs, T.xa, T.yofs, T.yb,
+                                 T.mode, pA, nullptr, pp, plane_stride, nullptr, false, false, false);
+        launch_resize_planes(st, dframes, n, h, w, frame_stride, row_stride, rw, rh, T.xofs, T.xa, T.yofs, T.yb, T.mode,
+                             pA + plane_stride, pB, pp, plane_stride, res, want_gh, want_ch, want_dct);
+    } else if (!resized) {
+        pA = gfull;                // slot 0 = prev0
+        pB = gfull + full_stride;  // batch frames only
+    }
+
+    // ---- DCT energy / temporal DCT (input: plane A)
+    if (want_dct || want_t) {
+        int mode = P.dct_mode;
+        if (mode == VQA_DCT_AUTO) mode = ((int64_t)ph * pw <= 128 * 128) ? VQA_DCT_FULL : VQA_DCT_BLOCK8;
+        if (mode == VQA_DCT_BLOCK8) {
+            const int pb = dct8_blocks_per_frame(ph, pw);
+            rc = ensure(c, c->partials, sizeof(double) * 2 * (size_t)pb * n);
+            if (rc) return rc;
+            prof_scope ps_(c, VQA_K_DCT8);
+            launch_dct8(st, pA, pp, plane_stride, n, ph, pw, want_dct, want_t, has_prev0, (double *)c->partials.p, res);
+        } else {
+            float *cw = nullptr, *ch = nullptr;
+            rc = get_dct_matrix(c, pw, &cw);
+            if (rc) return rc;
+            rc = get_dct_matrix(c, ph, &ch);
+            if (rc) return rc;
+            const size_t tiles = (size_t)((ph + 15) / 16) * ((pw + 15) / 16);
+            rc = ensure(c, c->dct_scratch, sizeof(float) * (size_t)ph * pw * n);
+            if (rc) return rc;
+            rc = ensure(c, c->dct_pe, sizeof(double) * tiles * n);
+            if (rc) return rc;
+            rc = ensure(c, c->dct_pt, sizeof(double) * tiles * n);
+            if (rc) return rc;
+            prof_scope ps_(c, VQA_K_DCT_FULL);
+            launch_dct_full(st, pA, pp, plane_stride, n, ph, pw, cw, ch, (float *)c->dct_scratch.p,
+                            (double *)c->dct_pe.p, (double *)c->dct_pt.p, want_dct, want_t, has_prev0, res);
+        }
+    }
+
+    // ---- block-SAD motion (full-resolution gray)
+    if (want_m) {
+        prof_scope ps_(c, VQA_K_SAD);
+        launch_block_sad(st, gfull, gp, full_stride, n, h, w, P.sad_range, has_prev0, res);
+    }
+
+    // ---- Canny (input: plane B)
+    c->last_has_state = false;
+    c->canny_rounds = 0;
+    if (want_e) {
+        const canny_geom g = canny_tiles(ph, pw);
+        const size_t ntiles = (size_t)g.tiles_x * g.tiles_y * n;
+        rc = ensure(c, c->state, (size_t)plane_stride * n);
+        if (rc) return rc;
+        rc = ensure(c, c->tile_flags, sizeof(uint32_t) * ntiles);
+        if (rc) return rc;
+        rc = ensure(c, c->dirty0, sizeof(uint32_t) * ntiles);
+        if (rc) return rc;
+        rc = ensure(c, c->dirty1, sizeof(uint32_t) * ntiles);
+        if (rc) return rc;
+        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 64);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->dirty0.p, 0, sizeof(uint32_t) * ntiles, st));
+        HIPCHK(c, hipMemsetAsync(c->dirty1.p, 0, sizeof(uint32_t) * ntiles, st));
+        int lo = P.canny_low, hi = P.canny_high;
+        if (lo > hi) { int t = lo; lo = hi; hi = t; }
+        {
+            prof_scope ps_(c, VQA_K_CANNY_NMS);
+            launch_canny_nms(st, pB, pp, plane_stride, n, ph, pw, lo, hi, (uint8_t *)c->state.p,
+                             (uint32_t *)c->tile_flags.p, res);
+        }
+        // hysteresis to the fixpoint: rounds in groups of 3, one 4-byte readback per group
+        uint32_t *dirty[2] = {(uint32_t *)c->dirty0.p, (uint32_t *)c->dirty1.p};
+        uint32_t *again = (uint32_t *)c->again_dev.p;
+        int round = 0;
+        const int GROUP = 3, MAX_ROUNDS = 1 << 20;
+        for (;;) {
+            HIPCHK(c, hipMemsetAsync(again, 0, sizeof(uint32_t) * GROUP, st));
+            for (int k = 0; k < GROUP; k++, round++) {
+                // round r reads dirty[r & 1] (written by round r-1) and writes dirty[(r + 1) & 1]
+                prof_scope ps_(c, VQA_K_CANNY_HYST);
+                launch_canny_hyst(st, (uint8_t *)c->state.p, pp, plane_stride, n, ph, pw, round,
+                                  (uint32_t *)c->tile_flags.p, dirty[round & 1], dirty[(round + 1) & 1], again + k, res);
+            }
+            HIPCHK(c, hipMemcpyAsync(c->again_host, again, sizeof(uint32_t) * GROUP, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (!c->again_host[GROUP - 1]) break;
+            if (round >= MAX_ROUNDS) { c->last_err = "canny hysteresis did not converge"; return VQA_ERR_HIP; }
+        }
+        c->canny_rounds = (uint32_t)round;
+        launch_canny_finish(st, n, res);
+        c->last_has_state = true;
+    }
+
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->res_host, c->res_dev.p, sizeof(vqa_frame_metrics) * (size_t)n, hipMemcpyDeviceToHost, st));
+    c->pend_c = n;
+    c->pend_c_prev0 = has_prev0;
+    c->last_n = n; c->last_h = h; c->last_w = w; c->last_ph = ph; c->last_pw = pw; c->last_pp = pp; c->last_gp = gp;
+    c->last_resized = resized; c->last_has_full = need_full; c->last_has_planes = need_planes;
+    return VQA_OK;
+}
+
+int vqa_complexity_wait(vqa_ctx *c, vqa_frame_metrics *out, int n)
+{
+    if (!c || !out) return VQA_ERR_INVALID;
+    if (!c->pend_c || n != c->pend_c) return VQA_ERR_STATE;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    memcpy(out, c->res_host, sizeof(vqa_frame_metrics) * (size_t)n);
+    for (int i = 0; i < n; i++) out[i].has_prev = (i > 0 || c->pend_c_prev0) ? 1u : 0u;
+    c->pend_c = 0;
+    return VQA_OK;
+}
+
+// ---------------------------------------------------------------------------
+int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int mem_kind, int n, int64_t ref_fs,
+                       int64_t dist_fs, const vqa_plane_desc *planes, int n_planes, int ssim_mode)
+{
+    if (!c || !ref || !dist || n <= 0 || !planes || n_planes <= 0 || n_planes > 4) return VQA_ERR_INVALID;
+    if (mem_kind != VQA_MEM_HOST && mem_kind != VQA_MEM_DEVICE) return VQA_ERR_INVALID;
+    if (ssim_mode != VQA_SSIM_GAUSS && ssim_mode != VQA_SSIM_FFMPEG) return VQA_ERR_INVALID;
+    if (c->pend_q) return VQA_ERR_STATE;
+    int64_t span = 0;
+    int maxblocks = 1;
+    for (int p = 0; p < n_planes; p++) {
+        const vqa_plane_desc &d = planes[p];
+        if (d.width <= 0 || d.height <= 0 || d.offset < 0 || d.pixel_step <= 0 ||
+            d.row_stride < (int64_t)d.width * d.pixel_step - (d.pixel_step - 1))
+            return VQA_ERR_INVALID;
+        if (ssim_mode == VQA_SSIM_GAUSS && (d.width < 11 || d.height < 11)) return VQA_ERR_UNSUPPORTED;
+        if (ssim_mode == VQA_SSIM_FFMPEG && (d.width < 8 || d.height < 8)) return VQA_ERR_UNSUPPORTED;
+        const int64_t end = d.offset + (int64_t)(d.height - 1) * d.row_stride + (int64_t)(d.width - 1) * d.pixel_step + 1;
+        span = end > span ? end : span;
+        const int b = ssim_mode == VQA_SSIM_GAUSS ? ssim_gauss_blocks(d.height, d.width) : ssim_ffmpeg_blocks(d.height, d.width);
+        maxblocks = b > maxblocks ? b : maxblocks;
+    }
+    if (n > 1 && (ref_fs < span || dist_fs < span)) return VQA_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const uint8_t *dref = ref, *ddist = dist;
+    if (mem_kind == VQA_MEM_HOST) {
+        const size_t rs = (size_t)(n - 1) * ref_fs + span, ds = (size_t)(n - 1) * dist_fs + span;
+        int rc = ensure(c, c->qstage_ref, rs);
+        if (rc) return rc;
+        rc = ensure(c, c->qstage_dist, ds);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->qstage_ref.p, ref, rs, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->qstage_dist.p, dist, ds, hipMemcpyHostToDevice, st));
+        dref = (const uint8_t *)c->qstage_ref.p;
+        ddist = (const uint8_t *)c->qstage_dist.p;
+    }
+    const size_t nent = (size_t)n * n_planes;
+    int rc = ensure(c, c->qres_dev, sizeof(vqa_plane_metrics) * nent);
+    if (rc) return rc;
+    rc = ensure_pinned(c, c->qres_host, c->qres_host_cap, sizeof(vqa_plane_metrics) * nent);
+    if (rc) return rc;
+    rc = ensure(c, c->qpartials, sizeof(double) * (size_t)maxblocks * n * n_planes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->qres_dev.p, 0, sizeof(vqa_plane_metrics) * nent, st));
+    vqa_plane_metrics *res = (vqa_plane_metrics *)c->qres_dev.p;
+    for (int p = 0; p < n_planes; p++) {
+        double *part = (double *)c->qpartials.p + (size_t)p * maxblocks * n;
+        prof_scope ps_(c, ssim_mode == VQA_SSIM_GAUSS ? VQA_K_SSIM_GAUSS : VQA_K_SSIM_FFMPEG);
+        if (ssim_mode == VQA_SSIM_GAUSS)
+            launch_quality_gauss(st, dref, ddist, n, ref_fs, dist_fs, planes[p], p, n_planes, part, res);
+        else
+            launch_quality_ffmpeg(st, dref, ddist, n, ref_fs, dist_fs, planes[p], p, n_planes, part, res);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->qres_host, c->qres_dev.p, sizeof(vqa_plane_metrics) * nent, hipMemcpyDeviceToHost, st));
+    c->pend_q = (int)nent;
+    return VQA_OK;
+}
+
+int vqa_quality_wait(vqa_ctx *c, vqa_plane_metrics *out, int n_entries)
+{
+    if (!c || !out) return VQA_ERR_INVALID;
+    if (!c->pend_q || n_entries != c->pend_q) return VQA_ERR_STATE;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    memcpy(out, c->qres_host, sizeof(vqa_plane_metrics) * (size_t)n_entries);
+    c->pend_q = 0;
+    return VQA_OK;
+}
+
+// ---------------------------------------------------------------------------
+int vqa_profile_enable(vqa_ctx *c, int on)
+{
+    if (!c) return VQA_ERR_INVALID;
+    c->prof_on = on != 0;
+    return VQA_OK;
+}
+
+int vqa_profile_read(vqa_ctx *c, int id, double *total_ms, int64_t *launches, int reset)
+{
+    if (!c || id < 0 || id >= VQA_K_COUNT) return VQA_ERR_INVALID;
+    if (!c->pend_c && !c->pend_q) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        prof_collect(c);
+    }
+    if (total_ms) *total_ms = c->prof_ms[id];
+    if (launches) *launches = c->prof_n[id];
+    if (reset) { c->prof_ms[id] = 0; c->prof_n[id] = 0; }
+    return VQA_OK;
+}
+
+const char *vqa_kernel_name(int id)
+{
+    static const char *names[VQA_K_COUNT] = {"k_bgr2gray_hist", "k_resize_planes", "k_dct8", "k_dct_full(gemm_nt x4)",
+                                             "k_canny_nms", "k_canny_hyst", "k_block_sad", "k_ssim_gauss",
+                                             "k_ssim_ffmpeg"};
+    return (id >= 0 && id < VQA_K_COUNT) ? names[id] : "?";
+}
+
+// ---------------------------------------------------------------------------
+int vqa_debug_read_plane(vqa_ctx *c, int which, int frame, uint8_t *dst, int dst_h, int dst_w)
+{
+    if (!c || !dst || frame < 0 || frame >= c->last_n) return VQA_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint8_t *src = nullptr;
+    int h = 0, w = 0, pitch = 0;
+    if (which == 3) {
+        if (!c->last_has_full) return VQA_ERR_STATE;
+        h = c->last_h; w = c->last_w; pitch = c->last_gp;
+        src = (const uint8_t *)c->gray_full.p + (int64_t)(frame + 1) * h * pitch;
+    } else if (which == 0 || which == 1) {
+        h = c->last_ph; w = c->last_pw; pitch = c->last_pp;
+        if (c->last_resized) {
+            if (!c->last_has_planes) return VQA_ERR_STATE;
+            src = which == 0 ? (const uint8_t *)c->planeA.p + (int64_t)(frame + 1) * h * pitch
+                             : (const uint8_t *)c->planeB.p + (int64_t)frame * h * pitch;
+        } else {
+            if (!c->last_has_full) return VQA_ERR_STATE;
+            src = (const uint8_t *)c->gray_full.p + (int64_t)(frame + 1) * h * pitch;
+        }
+    } else if (which == 2) {
+        if (!c->last_has_state) return VQA_ERR_STATE;
+        h = c->last_ph; w = c->last_pw; pitch = c->last_pp;
+        src = (const uint8_t *)c->state.p + (int64_t)frame * h * pitch;
+    } else {
+        return VQA_ERR_INVALID;
+    }
+    if (dst_h != h || dst_w != w) return VQA_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy2D(dst, (size_t)w, src, (size_t)pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost));
+    if (which == 2)
+        for (size_t i = 0; i < (size_t)h * w; i++) dst[i] = dst[i] == 2 ? 255 : 0;
+    return VQA_OK;
+}
+
+} // extern "C"

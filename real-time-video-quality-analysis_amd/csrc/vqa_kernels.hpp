@@ -1,0 +1,58 @@
+// vqa_kernels.hpp — host-side launchers of the gfx950 kernels (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vqa.h"
+
+namespace vqa {
+
+// k_gray_hist.hip
+void launch_bgr2gray_hist(hipStream_t st, const uint8_t *bgr, int n, int h, int w, int64_t frame_stride,
+                          int64_t row_stride, uint8_t *gray, int gp, int64_t plane_stride, vqa_frame_metrics *res,
+                          bool gray_hist, bool color_hist, bool sum2);
+void launch_resize_planes(hipStream_t st, const uint8_t *bgr, int n, int h, int w, int64_t frame_stride,
+                          int64_t row_stride, int rw, int rh, const int32_t *xofs, const int32_t *xa,
+                          const int32_t *yofs, const int32_t *yb, int mode, uint8_t *planeA, uint8_t *planeB, int pp,
+                          int64_t plane_stride, vqa_frame_metrics *res, bool gray_hist, bool color_hist, bool sum2);
+
+// k_dct8.hip
+int dct8_blocks_per_frame(int h, int w);
+void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
+                 bool energy, bool temporal, bool first_has_prev, double *partials, vqa_frame_metrics *res);
+
+// k_dct_full.hip
+void launch_dct_full(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
+                     const float *cw, const float *ch, float *scratch, double *pe, double *pt, bool energy,
+                     bool temporal, bool first_has_prev, vqa_frame_metrics *res);
+
+// k_canny.hip
+struct canny_geom {
+    int tiles_x, tiles_y;
+};
+canny_geom canny_tiles(int h, int w);
+void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int n, int h, int w,
+                      int low, int high, uint8_t *state, uint32_t *tile_flags, vqa_frame_metrics *res);
+// one hysteresis round; round 0 visits every tile holding weak pixels, later
+// rounds only tiles marked dirty by a neighbour.  *again (device) is set when
+// any tile marked a neighbour dirty.
+void launch_canny_hyst(hipStream_t st, uint8_t *state, int pitch, int64_t plane_stride, int n, int h, int w,
+                       int round, uint32_t *tile_flags, uint32_t *dirty_in, uint32_t *dirty_out, uint32_t *again,
+                       vqa_frame_metrics *res);
+void launch_canny_finish(hipStream_t st, int n, vqa_frame_metrics *res);
+
+// k_sad.hip
+void launch_block_sad(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
+                      int range, bool first_has_prev, vqa_frame_metrics *res);
+
+// k_quality.hip
+int ssim_gauss_blocks(int h, int w);
+void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dist, int n, int64_t ref_frame_stride,
+                          int64_t dist_frame_stride, const vqa_plane_desc &pd, int plane_index, int n_planes,
+                          double *partials, vqa_plane_metrics *res);
+void launch_quality_ffmpeg(hipStream_t st, const uint8_t *ref, const uint8_t *dist, int n, int64_t ref_frame_stride,
+                           int64_t dist_frame_stride, const vqa_plane_desc &pd, int plane_index, int n_planes,
+                           double *partials, vqa_plane_metrics *res);
+int ssim_ffmpeg_blocks(int h, int w);
+
+} // namespace vqa

@@ -1,0 +1,57 @@
+"""Temporal pooling of per-frame series — host-side float64 math.
+
+Mirrors smooth_data (complexity_metrics.py:114-125: pandas
+``Series.ewm(alpha=alpha).mean()``, adjust=True) followed by ``np.mean``
+(:302-309), and restates the pair as a fixed linear functional so a series
+sharded across GPUs can be pooled with one scalar all-reduce.
+"""
+import numpy as np
+
+
+def smooth_data(data, alpha=0.8):
+    """pandas ewm(alpha, adjust=True).mean():  y_t = sum_i (1-a)^i x_{t-i} / sum_i (1-a)^i."""
+    x = np.asarray(data, dtype=np.float64).reshape(-1)
+    out = np.empty_like(x)
+    num = 0.0
+    den = 0.0
+    decay = 1.0 - alpha
+    for i in range(x.size):
+        num = num * decay + x[i]
+        den = den * decay + 1.0
+        out[i] = num / den
+    return out
+
+
+def pooled_mean(data, alpha=0.8):
+    """np.mean(smooth_data(data)); NaN for an empty series, as np.mean([]) gives the reference."""
+    s = smooth_data(data, alpha)
+    if s.size == 0:
+        return float("nan")
+    return float(np.mean(s))
+
+
+def pooling_weights(T, alpha=0.8):
+    """c_i with mean(ewm(x)) == sum_i c_i x_i for a series of length T.
+
+    c_i = (1/T) sum_{t>=i} (1-a)^(t-i) / S_t,  S_t = sum_{j<=t} (1-a)^j.
+    Data-independent, so rank r can form sum_{i in shard r} c_i x_i from GLOBAL
+    indices and a SUM all-reduce of that one float64 gives the pooled value.
+    """
+    if T <= 0:
+        return np.zeros(0, np.float64)
+    decay = 1.0 - alpha
+    S = np.cumsum(decay ** np.arange(T, dtype=np.float64))
+    c = np.zeros(T, np.float64)
+    # c_i = (1/T) * sum_{t=i}^{T-1} decay^(t-i) / S_t   — backwards recurrence
+    acc = 0.0
+    for i in range(T - 1, -1, -1):
+        acc = acc * decay + 1.0 / S[i]
+        c[i] = acc / T
+    return c
+
+
+def shard_range(T, rank, world):
+    """Contiguous split of T items over `world` ranks (first T % world ranks get one more)."""
+    base, rem = divmod(T, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -1,0 +1,122 @@
+"""Host-side mirror of the reference's quality-metric surface
+(/root/reference/video_processing.py:145-177, :270-297), backed by the HIP engine.
+
+run_ffmpeg_metrics keeps the reference's contract: it takes the reference and the
+distorted stream plus the log paths, returns None and delivers its results as
+FFmpeg-format stats files, so extract_metrics_from_logs' regular expressions
+(:160, :166) parse them unchanged.  The streams are frame stacks (arrays / .npy)
+instead of container files: decode is out of scope.  VMAF is out of scope: no
+vmaf log is written, and — as in the reference when the file is absent (:169) —
+the 'VMAF' key is simply missing.
+"""
+import math
+import os
+import re
+
+import numpy as np
+
+from . import _native as N
+from .complexity_metrics import _open_frames, get_engine
+from .engine import DeviceFrames, bgr_planes, gray_planes, yuv420p_planes
+
+LAYOUTS = {
+    # name: (plane builder, component letters as FFmpeg prints them)
+    "bgr24": (bgr_planes, "bgr"),     # packed BGR24 frames [N,H,W,3]; FFmpeg labels RGB components r,g,b
+    "gray": (gray_planes, "y"),       # [N,H,W]
+    "yuv420p": (yuv420p_planes, "yuv"),  # [N, H*W*3/2] planar
+}
+
+
+def frame_quality(reference, distorted, layout="bgr24", ssim_mode="gauss", height=None, width=None, engine=None,
+                  batch_size=64):
+    """Per-frame SSE and SSIM per plane.  Returns (sse [n,p] uint64, ssim [n,p] float64, plane sizes)."""
+    eng = engine or get_engine()
+    mode = {"gauss": N.SSIM_GAUSS, "ffmpeg": N.SSIM_FFMPEG}[ssim_mode]
+    build, _ = LAYOUTS[layout]
+    if isinstance(reference, DeviceFrames):
+        h, w, n = reference.h, reference.w, reference.n
+    else:
+        reference = np.asarray(reference)
+        distorted = np.asarray(distorted)
+        n = reference.shape[0]
+        if layout == "yuv420p":
+            h, w = height, width
+        else:
+            h, w = reference.shape[1], reference.shape[2]
+    planes = build(h, w)
+    sse, ssim = [], []
+    for a in range(0, n, batch_size):
+        b = min(a + batch_size, n)
+        if isinstance(reference, DeviceFrames):
+            res = eng.quality(reference.slice(a, b), distorted.slice(a, b), planes, mode)
+        else:
+            res = eng.quality(reference[a:b], distorted[a:b], planes, mode)
+        sse.append(res["sse"])
+        ssim.append(res["ssim"])
+    sizes = [(p[0], p[1]) for p in planes]
+    return np.concatenate(sse), np.concatenate(ssim), sizes
+
+
+def _psnr(mse, peak=255.0):
+    # FFmpeg vf_psnr.c get_psnr(): 10*log10(max^2 / mse); mse == 0 -> inf
+    return 10.0 * math.log10(peak * peak / mse) if mse > 0 else float("inf")
+
+
+def psnr_stats_line(n, sse_row, sizes, comps):
+    """One line of FFmpeg's psnr stats_file (vf_psnr.c): per-component mse = sse/(w*h);
+    mse_avg weights components by plane area; 2-decimal text."""
+    areas = [w * h for w, h in sizes]
+    comp_mse = [float(s) / a for s, a in zip(sse_row, areas)]
+    total = float(sum(areas))
+    mse_avg = sum(m * (a / total) for m, a in zip(comp_mse, areas))
+    parts = ["n:%d mse_avg:%0.2f " % (n, mse_avg)]
+    parts += ["mse_%c:%0.2f " % (c, m) for c, m in zip(comps, comp_mse)]
+    parts.append("psnr_avg:%0.2f " % _psnr(mse_avg))
+    parts += ["psnr_%c:%0.2f " % (c, _psnr(m)) for c, m in zip(comps, comp_mse)]
+    return "".join(parts) + "\n"
+
+
+def ssim_stats_line(n, ssim_row, sizes, comps):
+    """One line of FFmpeg's ssim stats_file (vf_ssim.c): 'n:1 Y:0.99 U:.. V:.. All:0.99 (20.0)'."""
+    areas = [w * h for w, h in sizes]
+    total = float(sum(areas))
+    allv = sum(float(s) * (a / total) for s, a in zip(ssim_row, areas))
+    db = 10.0 * math.log10(1.0 / (1.0 - allv)) if allv < 1.0 else float("inf")
+    parts = ["n:%d " % n] + ["%c:%f " % (c.upper(), float(s)) for c, s in zip(comps, ssim_row)]
+    parts.append("All:%f (%f)\n" % (allv, db))
+    return "".join(parts)
+
+
+def run_ffmpeg_metrics(reference_video, distorted_video, psnr_log, ssim_log, vmaf_log, vmaf_model_path=None,
+                       layout="bgr24", ssim_mode="gauss", height=None, width=None):
+    """video_processing.py:270-297 — PSNR and SSIM between two streams, one stats line per frame."""
+    ref = _open_frames(reference_video) if layout == "bgr24" else reference_video
+    dist = _open_frames(distorted_video) if layout == "bgr24" else distorted_video
+    sse, ssim, sizes = frame_quality(ref, dist, layout, ssim_mode, height, width)
+    comps = LAYOUTS[layout][1]
+    # FFmpeg lists rgb components in r,g,b order whatever the packing
+    order = [2, 1, 0] if layout == "bgr24" else list(range(len(comps)))
+    names = "rgb" if layout == "bgr24" else comps
+    with open(psnr_log, "w") as f:
+        for i in range(sse.shape[0]):
+            f.write(psnr_stats_line(i + 1, [sse[i][j] for j in order], [sizes[j] for j in order], names))
+    with open(ssim_log, "w") as f:
+        for i in range(ssim.shape[0]):
+            f.write(ssim_stats_line(i + 1, [ssim[i][j] for j in order], [sizes[j] for j in order], names))
+    return None
+
+
+def extract_metrics_from_logs(psnr_log, ssim_log, vmaf_log, video_file, crf, bitrate, resolution, frame_rate):
+    """video_processing.py:145-177 — same keys, same regular expressions, first match only."""
+    metrics = {"Bitrate (kbps)": bitrate, "Resolution (px)": resolution, "Frame Rate (fps)": frame_rate, "CRF": crf}
+    if os.path.isfile(psnr_log):
+        with open(psnr_log) as f:
+            match = re.search(r"psnr_avg:(\s*\d+\.\d+)", f.read())
+            if match:
+                metrics["PSNR"] = float(match.group(1))
+    if os.path.isfile(ssim_log):
+        with open(ssim_log) as f:
+            match = re.search(r"All:(\s*\d+\.\d+)", f.read())
+            if match:
+                metrics["SSIM"] = float(match.group(1))
+    return metrics

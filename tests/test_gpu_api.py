@@ -1,0 +1,92 @@
+"""The reference-shaped Python surface on the GPU against the oracle's reference-shaped pipeline."""
+import functools
+import re
+
+import numpy as np
+import pytest
+
+from oracle import pipeline as pl
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _clip(n, h, w, seed=0):
+    from rtvqa_amd import synth
+    return synth.s_natural(n, h, w, seed=seed)
+
+
+def _close(a, b, exact=False):
+    if exact:
+        return a == b
+    return abs(float(a) - float(b)) <= RTOL * max(abs(float(b)), 1e-12)
+
+
+def test_per_frame_callables_match_reference_shaped_oracle():
+    from rtvqa_amd import complexity_metrics as cm
+    fr = _clip(3, 120, 160, seed=1)
+    f, p = fr[1], fr[0]
+    assert _close(cm.process_dct_frame(f, 64, 64), pl.process_dct_frame(f, 64, 64, "full"))
+    assert cm.process_histogram_frame(f, 64, 64) == pl.process_histogram_frame(f, 64, 64)
+    assert cm.process_color_histogram_frame(f, 64, 64) == pl.process_color_histogram_frame(f, 64, 64)
+    assert cm.process_edge_frame(f, 64, 64) == pl.process_edge_frame(f, 64, 64)
+    assert isinstance(cm.process_edge_frame(f, 64, 64), np.int64)
+    assert cm.process_frame_complexity((f, p)) == pl.process_frame_complexity((f, p))
+    assert cm.process_frame_complexity((f, None)) == 0.0
+    from oracle import c_oracle as co
+    pg, cg = co.resize_linear(co.bgr2gray(p), 64, 64), co.resize_linear(co.bgr2gray(f), 64, 64)
+    assert _close(cm.process_temporal_dct_frame(pg, cg, 64, 64), pl.process_temporal_dct_frame(pg, cg, 64, 64, "full"))
+
+
+def test_process_in_batches_known_kernels_and_order():
+    from rtvqa_amd import complexity_metrics as cm
+    fr = list(_clip(7, 72, 96, seed=2))
+    got = cm.process_in_batches(fr, functools.partial(cm.process_edge_frame, resize_width=48, resize_height=40), 4,
+                                batch_size=3)
+    want = [pl.process_edge_frame(f, 48, 40) for f in fr]
+    assert got == want
+    got = cm.process_in_batches(fr, cm.process_histogram_frame, 4, batch_size=100, resize_width=96, resize_height=72)
+    assert got == [pl.process_histogram_frame(f, 96, 72) for f in fr]
+    pairs = [(fr[i], fr[i - 1]) for i in range(1, 7)]
+    got = cm.process_in_batches(pairs, cm.process_frame_complexity, 2, batch_size=4)
+    assert got == [pl.process_frame_complexity(pr) for pr in pairs]
+    unchained = [(fr[0], fr[3]), (fr[5], None), (fr[2], fr[6])]
+    got = cm.process_in_batches(unchained, cm.process_frame_complexity, 2)
+    assert got == [pl.process_frame_complexity(pr) for pr in unchained]
+
+
+@pytest.mark.parametrize("interval,resize,n", [(10, (64, 64), 45), (1, (160, 120), 6), (10, (64, 64), 15)])
+def test_calculate_average_scene_complexity(interval, resize, n):
+    """config.json's configuration (64x64, interval 10) and a native-size interval-1 run."""
+    from rtvqa_amd import complexity_metrics as cm
+    fr = _clip(n, 120, 160, seed=3)
+    native = resize == (160, 120)
+    got = cm.calculate_average_scene_complexity(fr, resize[0], resize[1], frame_interval=interval, batch_size=2)
+    want = pl.calculate_average_scene_complexity(list(fr), resize[0], resize[1], frame_interval=interval,
+                                                 dct_mode="block8" if native else "full")
+    assert len(got) == 8
+    for k, (g, w_) in enumerate(zip(got, want)):
+        if isinstance(w_, float) and np.isnan(w_):
+            assert np.isnan(g), k
+        else:
+            assert _close(g, w_, exact=k in (3,)), (k, g, w_)
+
+
+def test_run_ffmpeg_metrics_files(tmp_path):
+    from rtvqa_amd import synth
+    from rtvqa_amd import video_processing as vp
+    from rtvqa_amd.engine import bgr_planes
+    ref = _clip(3, 72, 104, seed=4)
+    dist = synth.distort(ref)
+    dist[2] = ref[2]  # identical frame: PSNR inf
+    pl_, sl_ = str(tmp_path / "psnr.log"), str(tmp_path / "ssim.log")
+    assert vp.run_ffmpeg_metrics(ref, dist, pl_, sl_, str(tmp_path / "vmaf.json")) is None
+    m = vp.extract_metrics_from_logs(pl_, sl_, str(tmp_path / "vmaf.json"), "x", 23, 1000, "104x72", 30.0)
+    sse, ssim = pl.frame_quality(ref[0], dist[0], bgr_planes(72, 104), "gauss")
+    mse_avg = sum(sse) / (3.0 * 72 * 104)
+    assert m["PSNR"] == pytest.approx(10 * np.log10(255 ** 2 / mse_avg), abs=6e-3)   # 2-decimal text
+    assert m["SSIM"] == pytest.approx(sum(ssim) / 3, abs=2e-6)
+    assert "VMAF" not in m
+    lines = open(pl_).read().splitlines()
+    assert len(lines) == 3 and lines[2].startswith("n:3 mse_avg:0.00") and "psnr_avg:inf" in lines[2]
+    assert re.match(r"n:1 mse_avg:\d+\.\d\d mse_r:\d+\.\d\d mse_g:\d+\.\d\d mse_b:\d+\.\d\d psnr_avg:\d+\.\d\d ", lines[0])

@@ -1,0 +1,98 @@
+"""The device formulas in csrc/vqa_math.hpp, compiled for the host and checked against
+SciPy / the oracle (no GPU needed)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.fft
+
+from oracle import c_oracle as co
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("shim") / "libshim.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-ffp-contract=off", "-o", so,
+                           os.path.join(HERE, "host_math_shim.cpp")])
+    L = C.CDLL(so)
+    L.shim_dct8x8.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.shim_canny_classify.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    L.shim_ssim_moments.restype = C.c_float
+    L.shim_ssim_moments.argtypes = [C.c_float] * 4
+    L.shim_ssim_ffmpeg_end1.restype = C.c_float
+    return L
+
+
+def test_dct8x8_butterfly_matches_scipy(shim):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        x = rng.integers(-255, 256, (8, 8)).astype(np.float32)
+        y = np.empty((8, 8), np.float32)
+        shim.shim_dct8x8(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)))
+        ref = scipy.fft.dctn(x.astype(np.float64), norm="ortho")
+        assert np.abs(y - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    # asymmetric impulse: catches a transposed or permuted output
+    x = np.zeros((8, 8), np.float32)
+    x[1, 6] = 1
+    y = np.empty((8, 8), np.float32)
+    shim.shim_dct8x8(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.abs(y - scipy.fft.dctn(x.astype(np.float64), norm="ortho")).max() < 1e-6
+
+
+def test_gray_and_vcombine(shim):
+    rng = np.random.default_rng(1)
+    px = rng.integers(0, 256, (500, 3))
+    for b, g, r in px:
+        assert shim.shim_gray(int(b), int(g), int(r)) == (b * 3735 + g * 19235 + r * 9798 + 16384) >> 15
+    for _ in range(500):
+        s0, s1 = int(rng.integers(0, 255 * 2048 + 1)), int(rng.integers(0, 255 * 2048 + 1))
+        b0 = int(rng.integers(0, 2049))
+        b1 = 2048 - b0
+        assert shim.shim_vcombine(s0, s1, b0, b1) == ((((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2)
+
+
+def test_canny_classify_matches_oracle_maps(shim):
+    """Run the device NMS decision over whole images on the host and compare the
+    strong/weak counts with the oracle's Canny."""
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(2)
+    imgs = [rng.integers(0, 256, (40, 56), dtype=np.uint8)]
+    a = ndi.uniform_filter(rng.integers(0, 256, (60, 80)).astype(float), 7)
+    imgs.append(((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8))
+    for img in imgs:
+        h, w = img.shape
+        g = np.pad(img.astype(np.int32), 1, mode="edge")
+        s = lambda dy, dx: g[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+        gx = (s(-1, 1) + 2 * s(0, 1) + s(1, 1)) - (s(-1, -1) + 2 * s(0, -1) + s(1, -1))
+        gy = (s(1, -1) + 2 * s(1, 0) + s(1, 1)) - (s(-1, -1) + 2 * s(-1, 0) + s(-1, 1))
+        mag = np.pad(np.abs(gx) + np.abs(gy), 1)
+        strong = weak = 0
+        for y in range(h):
+            for x in range(w):
+                nb = (C.c_int * 8)(*[int(mag[y + 1 + dy, x + 1 + dx]) for dy in (-1, 0, 1) for dx in (-1, 0, 1)
+                                     if (dy, dx) != (0, 0)])
+                c = shim.shim_canny_classify(int(mag[y + 1, x + 1]), int(gx[y, x]), int(gy[y, x]), nb, 100, 200)
+                strong += c == 2
+                weak += c == 1
+        _, os_, ow = co.canny(img, 100, 200)
+        assert (strong, weak) == (os_, ow)
+
+
+def test_ssim_formulas(shim):
+    # identical windows -> exactly 1
+    assert shim.shim_ssim_moments(100.0, 100.0, 2 * (100.0 ** 2 + 50.0), 100.0 ** 2 + 50.0) == pytest.approx(1.0, abs=1e-6)
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        p = rng.integers(0, 256, 64)
+        q = np.clip(p + rng.integers(-20, 21, 64), 0, 255)
+        s1, s2 = int(p.sum()), int(q.sum())
+        ss, s12 = int((p * p).sum() + (q * q).sum()), int((p * q).sum())
+        v = shim.shim_ssim_ffmpeg_end1(s1, s2, ss, s12)
+        c1, c2 = 416, 235963
+        ref = (np.float32(2 * s1 * s2 + c1) * np.float32(2 * (s12 * 64 - s1 * s2) + c2)) / (
+            np.float32(s1 * s1 + s2 * s2 + c1) * np.float32(ss * 64 - s1 * s1 - s2 * s2 + c2))
+        assert abs(v - float(ref)) <= 2e-7 * abs(float(ref))

@@ -1,0 +1,215 @@
+"""Known-answer tests that pin the CPU oracle: theory-derived answers,
+plus agreement between the C restatement and the independent NumPy/SciPy one."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import np_oracle as no
+from oracle import pipeline as pl
+
+
+def _rng(seed=0):
+    return np.random.default_rng(seed)
+
+
+def _smooth(h, w, seed):
+    import scipy.ndimage as ndi
+    a = _rng(seed).integers(0, 256, (h + 16, w + 16)).astype(np.float64)
+    a = ndi.uniform_filter(a, 9)
+    a = (a - a.min()) / (a.max() - a.min()) * 255
+    return a[8:8 + h, 8:8 + w].astype(np.uint8)
+
+
+# ---- BGR2GRAY -------------------------------------------------------------
+def test_gray_coefficients_sum_and_identity():
+    # B=G=R=v -> v exactly (coefficients sum to 2^15)
+    v = np.arange(256, dtype=np.uint8)
+    bgr = np.repeat(v[None, :, None], 3, axis=2)
+    assert (co.bgr2gray(bgr)[0] == v).all()
+    # pure channels: round(255*c/32768)
+    for ch, coef in ((0, 3735), (1, 19235), (2, 9798)):
+        px = np.zeros((1, 1, 3), np.uint8)
+        px[0, 0, ch] = 255
+        assert co.bgr2gray(px)[0, 0] == (255 * coef + 16384) >> 15
+
+
+def test_gray_c_vs_numpy():
+    bgr = _rng(1).integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert (co.bgr2gray(bgr) == no.bgr2gray(bgr)).all()
+
+
+# ---- resize ---------------------------------------------------------------
+@pytest.mark.parametrize("dw,dh", [(64, 64), (45, 35), (33, 17), (200, 150), (90, 70), (1, 1)])
+def test_resize_c_vs_numpy(dw, dh):
+    bgr = _rng(2).integers(0, 256, (70, 90, 3), dtype=np.uint8)
+    assert (co.resize_linear(bgr, dw, dh) == no.resize_linear(bgr, dw, dh)).all()
+    g = co.bgr2gray(bgr)
+    assert (co.resize_linear(g, dw, dh) == no.resize_linear(g, dw, dh)).all()
+
+
+def test_resize_identity_constant_and_half():
+    img = _rng(3).integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    assert (co.resize_linear(img, 64, 48) == img).all()                       # dsize == ssize: copy
+    const = np.full((1080 // 8, 1920 // 8, 3), 77, np.uint8)
+    assert (co.resize_linear(const, 64, 64) == 77).all()                      # weights sum to 2048
+    half = co.resize_linear(img, 32, 24)                                      # exact 2x: INTER_AREA fast path
+    ref = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
+    assert (half == ref).all()
+
+
+def test_resize_tables_1080p_to_64():
+    ofs, coef = co.resize_tables(1920, 64, True)
+    # scale 30: fx = (dx+0.5)*30-0.5 = 14.5 + 30 dx  -> sx = 14+30dx, weights (1024,1024)
+    assert (ofs == 14 + 30 * np.arange(64)).all()
+    assert (coef == 1024).all()
+    ofs, coef = co.resize_tables(1080, 64, False)
+    assert (coef.sum(axis=1) == 2048).all()
+    assert ofs[0] == 7 and ofs[-1] == int(np.floor(63.5 * 16.875 - 0.5))
+
+
+# ---- DCT ------------------------------------------------------------------
+def test_dct_full_vs_scipy_and_parseval():
+    g = _rng(4).integers(0, 256, (64, 64), dtype=np.uint8)
+    y = co.dct2_full(g.astype(np.float32))
+    y2 = no.dct2_full(g)
+    assert np.abs(y - y2).max() <= 2e-7 * np.abs(y2).max() + 1e-3
+    exact = float((g.astype(np.int64) ** 2).sum())
+    assert abs(co.dct_energy_full(g) - exact) <= 1e-6 * exact
+    e8, _, _ = co.dct8x8(None, g)
+    assert abs(e8 - exact) <= 1e-9 * exact
+    # ragged size: zero-padded partial blocks keep Parseval
+    g2 = _rng(5).integers(0, 256, (37, 51), dtype=np.uint8)
+    e8, _, _ = co.dct8x8(None, g2)
+    assert abs(e8 - float((g2.astype(np.int64) ** 2).sum())) <= 1e-9 * e8
+    assert abs(no.dct8x8(None, g2)[0] - e8) <= 1e-9 * e8
+
+
+def test_temporal_dct_constants():
+    h, w = 64, 64
+    a = np.full((h, w), 100, np.uint8)
+    b = np.full((h, w), 97, np.uint8)
+    # full frame: only the DC coefficient differs: |c1-c2| * sqrt(W*H)
+    assert abs(co.temporal_dct_full(a, b) - 3 * np.sqrt(h * w)) < 1e-3
+    # 8x8 blocks: one DC per block: |c1-c2| * 8 per block = |c1-c2| * W*H/8
+    _, l1, l1f = co.dct8x8(a, b)
+    assert abs(l1 - 3 * h * w / 8) < 1e-6 and abs(l1f - l1) < 1e-2
+    assert co.temporal_dct_full(a, a) == 0.0 and co.dct8x8(a, a)[1] == 0.0
+
+
+def test_temporal_dct8_c_vs_numpy_and_f32_noise():
+    p, c = _smooth(72, 88, 1), _smooth(72, 88, 2)
+    _, l1, l1f = co.dct8x8(p, c)
+    assert abs(l1 - no.dct8x8(p, c)[1]) <= 1e-9 * l1
+    assert abs(l1f - l1) <= 1e-4 * l1  # the reference's f32 arithmetic stays inside the tolerance
+
+
+# ---- histograms / entropy ---------------------------------------------------
+def test_hist_and_entropy_known_answers():
+    ramp = np.tile(np.arange(256, dtype=np.uint8), 16)
+    assert (co.hist_u8(ramp) == 16).all()
+    assert no.gray_entropy_from_counts(co.hist_u8(ramp)) == np.float32(8.0)
+    const = np.full(4096, 9, np.uint8)
+    assert no.gray_entropy_from_counts(co.hist_u8(const)) == 0.0
+    # three exactly-uniform channels: 24 bits minus the +1e-8 inside the log, in float32
+    ce = no.color_entropy_from_counts([co.hist_u8(ramp)] * 3)
+    assert ce == np.float32(23.999994)
+    bgr = _rng(6).integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    for ch in range(3):
+        assert (co.hist_u8(bgr, offset=ch, step=3) == no.hist_u8(bgr[..., ch])).all()
+
+
+# ---- Canny ----------------------------------------------------------------
+def test_canny_known_answers():
+    assert co.canny(np.full((32, 48), 120, np.uint8))[0] == 0
+    h, w = 40, 64
+    step = np.where(np.arange(w)[None, :] < w // 2, 40, 200).astype(np.uint8).repeat(h, 0)
+    cnt, strong, weak, edges = co.canny(step, 100, 200, want_map=True)
+    # a vertical step >= 51 grey levels: Sobel response 4*delta > 200 on the two columns
+    # flanking the step; NMS (m > left && m >= right) keeps exactly one of them -> H pixels
+    assert cnt == h and strong == h and weak == 0
+    assert (edges.sum(axis=0) > 0).sum() == 1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_canny_c_vs_numpy(seed):
+    img = _smooth(120, 160, seed) if seed % 2 == 0 else _rng(seed).integers(0, 256, (97, 131), dtype=np.uint8)
+    c = co.canny(img, 100, 200, want_map=True)
+    n = no.canny(img, 100, 200)
+    assert c[:3] == n[:3] and (c[3] == n[3]).all()
+    lo = co.canny(img, 20, 60, want_map=True)
+    ln = no.canny(img, 20, 60)
+    assert lo[:3] == ln[:3] and (lo[3] == ln[3]).all()
+
+
+# ---- block SAD ----------------------------------------------------------------
+@pytest.mark.parametrize("dy,dx", [(0, 0), (2, -3), (-7, 7), (5, 0)])
+def test_block_sad_pan(dy, dx):
+    base = _smooth(160, 200, 7)
+    prev = base[16:16 + 96, 16:16 + 128]
+    curr = base[16 - dy:16 - dy + 96, 16 - dx:16 - dx + 128]  # curr[y][x] = prev[y-dy][x-dx] -> mv = (-dy,-dx)
+    nb, sad, hist, mv = co.block_sad(prev, curr, 7, want_mv=True)
+    nby, nbx = 96 // 16, 128 // 16
+    assert nb == nby * nbx
+    mv = mv.reshape(nby, nbx, 2)
+    assert (mv[1:-1, 1:-1, 0] == -dy).all() and (mv[1:-1, 1:-1, 1] == -dx).all()
+    n2 = no.block_sad(prev, curr, 7)
+    assert n2[0] == nb and n2[1] == sad and (n2[2] == hist).all() and (n2[3] == mv.reshape(-1, 2)).all()
+
+
+def test_block_sad_noise_and_tiebreak():
+    p = _rng(8).integers(0, 256, (64, 80), dtype=np.uint8)
+    c = _rng(9).integers(0, 256, (64, 80), dtype=np.uint8)
+    a = co.block_sad(p, c, 7, want_mv=True)
+    b = no.block_sad(p, c, 7)
+    assert a[1] == b[1] and (a[2] == b[2]).all() and (a[3] == b[3]).all()
+    # constant frames: every candidate ties at SAD 0 -> zero vector wins (min dx^2+dy^2)
+    z = np.full((48, 48), 5, np.uint8)
+    nb, sad, hist = co.block_sad(z, z, 7)
+    assert sad == 0 and hist[0] == nb == 9
+    # too small for a block
+    assert co.block_sad(z[:10], z[:10], 7)[0] == 0
+
+
+# ---- PSNR / SSIM ----------------------------------------------------------------
+def test_sse_and_psnr_known_answer():
+    r = _rng(10).integers(0, 255, (33, 47), dtype=np.uint8)
+    d = r + 1
+    assert co.sse_plane(r, d) == r.size
+    assert abs(10 * np.log10(255 ** 2 / 1.0) - 48.1308) < 1e-4
+
+
+def test_ssim_known_answers_and_cross_checks():
+    r = _smooth(60, 90, 11)
+    assert co.ssim_gauss(r, r) == 1.0 and co.ssim_ffmpeg(r, r) == 1.0
+    d = np.clip(r.astype(int) + _rng(12).integers(-6, 7, r.shape), 0, 255).astype(np.uint8)
+    assert abs(co.ssim_gauss(r, d) - no.ssim_gauss(r, d)) < 1e-12
+    assert abs(co.ssim_ffmpeg(r, d) - no.ssim_ffmpeg(r, d)) < 1e-12
+    g = co.gauss11()
+    assert abs(g.sum() - 1) < 1e-15 and g.argmax() == 5 and np.allclose(g, g[::-1])
+    # packed-BGR channel views (pixel step 3)
+    R = _rng(13).integers(0, 256, (40, 52, 3), dtype=np.uint8)
+    D = np.clip(R.astype(int) + _rng(14).integers(-9, 10, R.shape), 0, 255).astype(np.uint8)
+    for ch in range(3):
+        a, b = np.ascontiguousarray(R[..., ch]), np.ascontiguousarray(D[..., ch])
+        assert co.sse_plane(R[..., ch], D[..., ch]) == no.sse_plane(a, b)
+        assert abs(co.ssim_gauss(R[..., ch], D[..., ch]) - co.ssim_gauss(a, b)) < 1e-15
+    assert np.isnan(co.ssim_gauss(r[:10], r[:10]))
+
+
+# ---- pooling + whole pipeline shape ------------------------------------------------
+def test_ewm_matches_survey_pin():
+    sm = no.ewm_mean([1, 4, 2, 8, 5], 0.8)
+    assert np.allclose(sm, [1, 3.5, 2.29032258, 6.86538462, 5.37259923], atol=1e-8)
+    assert abs(sm.mean() - 3.8056612855567877) < 1e-14
+
+
+def test_pipeline_sample_counts_and_order():
+    frames = list(_rng(15).integers(0, 256, (45, 48, 64, 3), dtype=np.uint8))
+    out, series = pl.calculate_average_scene_complexity(frames, 32, 32, frame_interval=10, return_series=True)
+    # 45 frames, interval 10 -> selected 9,19,29,39 -> T=4: 3 per-frame samples, 2 temporal samples
+    assert len(series["dct"]) == 3 and len(series["motion"]) == 3 and len(series["temporal"]) == 2
+    assert len(out) == 8 and np.isnan(out[4])
+    assert abs(out[7] - 3.0) < 1e-9  # 30 fps / interval 10
+    # too short a clip: empty series -> NaN means, temporal 0.0 (:541)
+    out0 = pl.calculate_average_scene_complexity(frames[:15], 32, 32, frame_interval=10)
+    assert np.isnan(out0[1]) and out0[6] == 0.0
