@@ -69,7 +69,11 @@ def cpu_baseline(ref, dist, full, sample):
     from concurrent.futures import ProcessPoolExecutor
     from oracle import c_oracle as co
     co.build()
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))  # this job's CPU share, not the whole host
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("VQA_CPU_CORES", "16")))  # a 1-GPU box's share is 16 cores
     workers = max(1, cores // 2)  # complexity_metrics.py:264-265
     items = [(ref[i], dist[i], dist[i - 1] if i else dist[0], full) for i in range(sample)]
     t0 = time.perf_counter()
