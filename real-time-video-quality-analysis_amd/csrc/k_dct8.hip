@@ -19,6 +19,8 @@
 #include "vqa_kernels.hpp"
 #include "vqa_math.hpp"
 
+#include <cstdlib>
+
 namespace vqa {
 
 __device__ __forceinline__ void load_block_u8(const uint8_t *__restrict__ plane, int pitch, int h, int w, int by,
@@ -43,8 +45,8 @@ __device__ __forceinline__ float ub(uint32_t v, int k) { return (float)((v >> (8
 // grid = (blocks_per_frame, n_frames), block = 256 (4 independent waves).
 // planes: slot 0 = frame preceding the batch, slot i+1 = batch frame i.
 // partials[(f * gridDim.x + blockIdx.x) * 2 + {0,1}] = {energy, temporal L1} of this block's share.
-template <bool ENERGY, bool TEMPORAL>
-__global__ __launch_bounds__(256) void k_dct8(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride,
+template <bool ENERGY, bool TEMPORAL, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_dct8(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride,
                                               int h, int w, int first_has_prev, double *__restrict__ partials)
 {
     __shared__ double red[4];
@@ -72,6 +74,8 @@ __global__ __launch_bounds__(256) void k_dct8(const uint8_t *__restrict__ planes
             for (int i = 0; i < 64; i++) e = fmaf(v[i], v[i], e);
             acc_e += (double)e;
         }
+        // the two transforms reuse the same 64 registers: do not let the scheduler interleave them
+        if (MINW > 1) __builtin_amdgcn_sched_barrier(0);
         if (temporal) {
             uint32_t plo[8], phi[8];
             load_block_u8(prev, pitch, h, w, by, bx, plo, phi);
@@ -119,21 +123,44 @@ int dct8_blocks_per_frame(int h, int w)
     return pb < 1 ? 1 : (pb > 64 ? 64 : pb);
 }
 
+static int dct_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("VQA_DCT_VARIANT");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 2) v = 0;
+    }
+    return v;
+}
+
+template <int MINW>
+static void launch_dct8_v(hipStream_t st, dim3 grid, const uint8_t *planes, int pitch, int64_t plane_stride, int h, int w,
+                          bool energy, bool temporal, bool first_has_prev, double *partials)
+{
+    dim3 block(256);
+    if (energy && temporal)
+        hipLaunchKernelGGL((k_dct8<true, true, MINW>), grid, block, 0, st, planes, pitch, plane_stride, h, w,
+                           (int)first_has_prev, partials);
+    else if (energy)
+        hipLaunchKernelGGL((k_dct8<true, false, MINW>), grid, block, 0, st, planes, pitch, plane_stride, h, w,
+                           (int)first_has_prev, partials);
+    else
+        hipLaunchKernelGGL((k_dct8<false, true, MINW>), grid, block, 0, st, planes, pitch, plane_stride, h, w,
+                           (int)first_has_prev, partials);
+}
+
 void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
                  bool energy, bool temporal, bool first_has_prev, double *partials, vqa_frame_metrics *res)
 {
     if (n <= 0 || (!energy && !temporal)) return;
     const int pb = dct8_blocks_per_frame(h, w);
-    dim3 grid(pb, n), block(256);
-    if (energy && temporal)
-        hipLaunchKernelGGL((k_dct8<true, true>), grid, block, 0, st, planes, pitch, plane_stride, h, w,
-                           (int)first_has_prev, partials);
-    else if (energy)
-        hipLaunchKernelGGL((k_dct8<true, false>), grid, block, 0, st, planes, pitch, plane_stride, h, w,
-                           (int)first_has_prev, partials);
-    else
-        hipLaunchKernelGGL((k_dct8<false, true>), grid, block, 0, st, planes, pitch, plane_stride, h, w,
-                           (int)first_has_prev, partials);
+    dim3 grid(pb, n);
+    switch (dct_variant()) { // A/B knob (VQA_DCT_VARIANT): min waves/SIMD 3 (default), 1, 4
+    case 1: launch_dct8_v<1>(st, grid, planes, pitch, plane_stride, h, w, energy, temporal, first_has_prev, partials); break;
+    case 2: launch_dct8_v<4>(st, grid, planes, pitch, plane_stride, h, w, energy, temporal, first_has_prev, partials); break;
+    default: launch_dct8_v<3>(st, grid, planes, pitch, plane_stride, h, w, energy, temporal, first_has_prev, partials); break;
+    }
     hipLaunchKernelGGL(k_dct_finalize, dim3((n + 63) / 64), dim3(64), 0, st, partials, pb, n, res, (int)energy,
                        (int)temporal, (int)first_has_prev);
 }

@@ -29,32 +29,24 @@
 #include "vqa_kernels.hpp"
 #include "vqa_math.hpp"
 
+#include <cstdlib>
+
 namespace vqa {
 
-constexpr int QT = 256;
-constexpr int QCOLS = 2 * QT;    // input columns per workgroup
-constexpr int QOUT = QCOLS - 10; // output columns per workgroup
-constexpr int QS = 128;          // output rows per strip
+constexpr int QS = 256;          // output rows per strip
 
-#define GW(k)                                                                                                        \
-    ((k) == 0 || (k) == 10 ? 1.028380124e-03f                                                                        \
-     : (k) == 1 || (k) == 9 ? 7.598758209e-03f                                                                       \
-     : (k) == 2 || (k) == 8 ? 3.600077331e-02f                                                                       \
-     : (k) == 3 || (k) == 7 ? 1.093606874e-01f                                                                       \
-     : (k) == 4 || (k) == 6 ? 2.130055428e-01f                                                                       \
-                            : 2.660117149e-01f)
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-struct px2 {
-    uint32_t r0, r1, d0, d1;
-};
-
-__device__ __forceinline__ px2 load_px2(const uint8_t *__restrict__ rrow, const uint8_t *__restrict__ drow, int x,
-                                        int w, int step)
+// 11-tap Gaussian, sigma 1.5, normalised in double and rounded to float (oracle: vqo_gauss11)
+__host__ __device__ constexpr float gw(int k)
 {
-    px2 p = {128u, 128u, 128u, 128u}; // out-of-plane columns never reach a valid output
-    if (x < w) { p.r0 = rrow[(int64_t)x * step]; p.d0 = drow[(int64_t)x * step]; }
-    if (x + 1 < w) { p.r1 = rrow[(int64_t)(x + 1) * step]; p.d1 = drow[(int64_t)(x + 1) * step]; }
-    return p;
+    return (k < 0 || k > 10) ? 0.f
+           : (k == 0 || k == 10) ? 1.028380124e-03f
+           : (k == 1 || k == 9) ? 7.598758209e-03f
+           : (k == 2 || k == 8) ? 3.600077331e-02f
+           : (k == 3 || k == 7) ? 1.093606874e-01f
+           : (k == 4 || k == 6) ? 2.130055428e-01f
+                                : 2.660117149e-01f;
 }
 
 __device__ __forceinline__ float ssim_centered(float mx, float my, float sq, float xy)
@@ -69,99 +61,109 @@ __device__ __forceinline__ float ssim_centered(float mx, float my, float sq, flo
     return num * __builtin_amdgcn_rcpf(den);
 }
 
-// grid = (ncb * nstrips, n_frames)
+// Up to 4 planes of identical geometry (e.g. the B, G, R channels of packed BGR24) are
+// handled by ONE launch: the plane index is the fastest-varying part of blockIdx.x, so the
+// workgroups that touch the same cache lines are dispatched together and share them in L2.
+struct plane_group {
+    int64_t offset[4];
+    int plane_index[4];
+    int count;
+};
+
+// One column per thread; the four moment maps ride in two float2 registers
+// (E[x],E[y]) and (E[x^2+y^2],E[xy]), so every tap is two v_pk_fma_f32.  The rolling
+// accumulator file is 11 slots x 2 float2 = 44 VGPRs (80 VGPRs in all: 6 waves/SIMD).
+// PF = how many rows ahead the pixel loads run.
+// grid = (ncb * nstrips * group.count, n_frames)
+template <int QT, int PF>
 __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dist,
-                                                   int64_t ref_fs, int64_t dist_fs, int64_t offset,
-                                                   int64_t row_stride, int step, int w, int h, int ncb, int nstrips,
-                                                   double *__restrict__ partials, int plane_index, int n_planes,
-                                                   vqa_plane_metrics *__restrict__ res)
+                                                   int64_t ref_fs, int64_t dist_fs, plane_group g, int64_t row_stride,
+                                                   int step, int w, int h, int ncb, int nstrips,
+                                                   double *__restrict__ partials, int64_t partial_plane_stride,
+                                                   int n_planes, vqa_plane_metrics *__restrict__ res)
 {
-    __shared__ float4 vb[2][2][QT]; // [row buffer][column parity][column / 2]
+    constexpr int QOUT = QT - 10; // output columns per workgroup
+    __shared__ float4 vb[2][QT];  // [row buffer][column] = (E[x], E[y], E[x^2+y^2], E[xy]) after the vertical pass
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
     const int f = blockIdx.y;
     const int t = threadIdx.x;
-    const int cb = blockIdx.x % ncb, sb = blockIdx.x / ncb;
+    const int ch = blockIdx.x % g.count, tile = blockIdx.x / g.count;
+    const int cb = tile % ncb, sb = tile / ncb;
     const int xs = cb * QOUT, ys = sb * QS;
-    const int xin = xs + 2 * t;
-    const int ow = w - 10, oh = h - 10;
+    const int xin = xs + t;
+    const int ow = w - 10;
     const int nrows = min(QS + 10, h - ys);
     const bool last_cb = cb == ncb - 1, last_sb = sb == nstrips - 1;
-    const bool own_c0 = (xin < w) && (last_cb || 2 * t < QOUT);
-    const bool own_c1 = (xin + 1 < w) && (last_cb || 2 * t + 1 < QOUT);
-    const bool out_c0 = (2 * t < QOUT) && (xin < ow);
-    const bool out_c1 = (2 * t + 1 < QOUT) && (xin + 1 < ow);
-    const uint8_t *rbase = ref + (int64_t)f * ref_fs + offset + (int64_t)ys * row_stride;
-    const uint8_t *dbase = dist + (int64_t)f * dist_fs + offset + (int64_t)ys * row_stride;
+    const bool in_c = xin < w;
+    const bool own_c = in_c && (last_cb || t < QOUT);
+    const bool out_c = (t < QOUT) && (xin < ow);
+    const int64_t base = g.offset[ch] + (int64_t)ys * row_stride + (int64_t)(in_c ? xin : 0) * step;
+    const uint8_t *rp = ref + (int64_t)f * ref_fs + base;
+    const uint8_t *dp = dist + (int64_t)f * dist_fs + base;
 
-    float acc[2][4][11];
+    f2 acc[2][11];
 #pragma unroll
-    for (int e = 0; e < 2; e++)
+    for (int m = 0; m < 2; m++)
 #pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int s = 0; s < 11; s++) acc[e][m][s] = 0.f;
+        for (int s = 0; s < 11; s++) acc[m][s] = f2{0.f, 0.f};
     float ssim_acc = 0.f;
     uint32_t sse_acc = 0;
 
-    px2 nxt = load_px2(rbase, dbase, xin, w, step);
+    // pixel loads run PF rows ahead of the arithmetic (a shift register of PF byte pairs)
+    uint32_t qr[PF], qd[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+        const int rr = min(i, nrows - 1);
+        qr[i] = rp[(int64_t)rr * row_stride];
+        qd[i] = dp[(int64_t)rr * row_stride];
+    }
     for (int r0 = 0; r0 < nrows; r0 += 11) {
 #pragma unroll
         for (int p = 0; p < 11; p++) {
             const int r = r0 + p;
             if (r < nrows) {
-                const px2 cur = nxt;
-                if (r + 1 < nrows)
-                    nxt = load_px2(rbase + (int64_t)(r + 1) * row_stride, dbase + (int64_t)(r + 1) * row_stride, xin, w,
-                                   step);
-                const bool own_row = last_sb || r < QS;
-                if (own_row) {
-                    const int e0 = (int)cur.r0 - (int)cur.d0, e1 = (int)cur.r1 - (int)cur.d1;
-                    if (own_c0) sse_acc += (uint32_t)(e0 * e0);
-                    if (own_c1) sse_acc += (uint32_t)(e1 * e1);
-                }
-                float v[2][4];
+                const uint32_t cr = qr[0], cd = qd[0];
+#pragma unroll
+                for (int i = 0; i + 1 < PF; i++) { qr[i] = qr[i + 1]; qd[i] = qd[i + 1]; }
                 {
-                    const float x0 = (float)((int)cur.r0 - 128), y0 = (float)((int)cur.d0 - 128);
-                    const float x1 = (float)((int)cur.r1 - 128), y1 = (float)((int)cur.d1 - 128);
-                    v[0][0] = x0; v[0][1] = y0; v[0][2] = fmaf(x0, x0, y0 * y0); v[0][3] = x0 * y0;
-                    v[1][0] = x1; v[1][1] = y1; v[1][2] = fmaf(x1, x1, y1 * y1); v[1][3] = x1 * y1;
+                    const int rr = min(r + PF, nrows - 1);
+                    qr[PF - 1] = rp[(int64_t)rr * row_stride];
+                    qd[PF - 1] = dp[(int64_t)rr * row_stride];
                 }
+                if (own_c && (last_sb || r < QS)) {
+                    const int e = (int)cr - (int)cd;
+                    sse_acc += (uint32_t)(e * e);
+                }
+                const f2 xy = f2{(float)cr, (float)cd} - f2{128.f, 128.f};
+                f2 v1 = xy.xx * xy;                                        // (x^2, x y)
+                v1 = __builtin_elementwise_fma(f2{xy.y, 0.f}, xy.yy, v1); // (x^2 + y^2, x y)
                 // vertical pass: input row r is tap k of output row r-k, kept in slot (r-k) mod 11
 #pragma unroll
-                for (int e = 0; e < 2; e++)
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-#pragma unroll
-                        for (int k = 0; k < 11; k++) {
-                            const int s = (p - k + 11) % 11;
-                            if (k == 0) acc[e][m][s] = GW(0) * v[e][m];
-                            else acc[e][m][s] = fmaf(GW(k), v[e][m], acc[e][m][s]);
-                        }
+                for (int k = 0; k < 11; k++) {
+                    const int s = (p - k + 11) % 11;
+                    if (k == 0) {
+                        acc[0][s] = gw(0) * xy;
+                        acc[1][s] = gw(0) * v1;
+                    } else {
+                        acc[0][s] = __builtin_elementwise_fma(f2{gw(k), gw(k)}, xy, acc[0][s]);
+                        acc[1][s] = __builtin_elementwise_fma(f2{gw(k), gw(k)}, v1, acc[1][s]);
                     }
+                }
                 if (r >= 10) {
                     const int s = (p + 1) % 11; // slot of output row o = r - 10, now complete
-                    const int o = r - 10;
-                    const int buf = o & 1;
-                    vb[buf][0][t] = make_float4(acc[0][0][s], acc[0][1][s], acc[0][2][s], acc[0][3][s]);
-                    vb[buf][1][t] = make_float4(acc[1][0][s], acc[1][1][s], acc[1][2][s], acc[1][3][s]);
+                    const int buf = (r - 10) & 1;
+                    vb[buf][t] = make_float4(acc[0][s].x, acc[0][s].y, acc[1][s].x, acc[1][s].y);
                     __syncthreads();
-                    if (out_c0 && ys + o < oh) {
-                        float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (out_c) {
+                        f2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
 #pragma unroll
-                        for (int k = 0; k < 12; k++) {
-                            const float4 q = vb[buf][k & 1][t + (k >> 1)];
-                            if (k < 11) {
-                                o0[0] = fmaf(GW(k), q.x, o0[0]); o0[1] = fmaf(GW(k), q.y, o0[1]);
-                                o0[2] = fmaf(GW(k), q.z, o0[2]); o0[3] = fmaf(GW(k), q.w, o0[3]);
-                            }
-                            if (k > 0) {
-                                o1[0] = fmaf(GW(k - 1), q.x, o1[0]); o1[1] = fmaf(GW(k - 1), q.y, o1[1]);
-                                o1[2] = fmaf(GW(k - 1), q.z, o1[2]); o1[3] = fmaf(GW(k - 1), q.w, o1[3]);
-                            }
+                        for (int k = 0; k < 11; k++) {
+                            const float4 q = vb[buf][t + k];
+                            o0 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.x, q.y}, o0);
+                            o1 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.z, q.w}, o1);
                         }
-                        ssim_acc += ssim_centered(o0[0], o0[1], o0[2], o0[3]);
-                        if (out_c1) ssim_acc += ssim_centered(o1[0], o1[1], o1[2], o1[3]);
+                        ssim_acc += ssim_centered(o0.x, o0.y, o1.x, o1.y);
                     }
                 }
             }
@@ -170,8 +172,9 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
     const double bs = block_sum((double)ssim_acc, red);
     const unsigned long long be = block_sum_u64((unsigned long long)sse_acc, redu);
     if (t == 0) {
-        partials[(int64_t)f * gridDim.x + blockIdx.x] = bs;
-        if (be) atomicAdd((unsigned long long *)&res[(int64_t)f * n_planes + plane_index].sse, be);
+        const int pidx = g.plane_index[ch];
+        partials[(int64_t)pidx * partial_plane_stride + (int64_t)f * (gridDim.x / g.count) + tile] = bs;
+        if (be) atomicAdd((unsigned long long *)&res[(int64_t)f * n_planes + pidx].sse, be);
     }
 }
 
@@ -185,25 +188,58 @@ __global__ void k_ssim_finalize(const double *__restrict__ partials, int bpp, in
     res[(int64_t)f * n_planes + plane_index].ssim = s * inv_count;
 }
 
+// A/B knob for tuning runs (VQA_SSIM_VARIANT): 0 = {256 threads, prefetch 2} (default), 1 = {256, 1},
+// 2 = {256, 3}, 3 = {256, 4}, 4 = {128, 3}
+static int ssim_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("VQA_SSIM_VARIANT");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 4) v = 0;
+    }
+    return v;
+}
+static int ssim_qout() { return (ssim_variant() == 4 ? 128 : 256) - 10; }
+
 int ssim_gauss_blocks(int h, int w)
 {
     if (h < 11 || w < 11) return 0;
-    const int ncb = (w - 10 + QOUT - 1) / QOUT, ns = (h - 10 + QS - 1) / QS;
+    const int qout = ssim_qout();
+    const int ncb = (w - 10 + qout - 1) / qout, ns = (h - 10 + QS - 1) / QS;
     return ncb * ns;
 }
 
+// planes[idx[0..count)] share width, height, row_stride and pixel_step
 void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dist, int n, int64_t ref_frame_stride,
-                          int64_t dist_frame_stride, const vqa_plane_desc &pd, int plane_index, int n_planes,
-                          double *partials, vqa_plane_metrics *res)
+                          int64_t dist_frame_stride, const vqa_plane_desc *planes, const int *idx, int count,
+                          int n_planes, double *partials, int64_t partial_plane_stride, vqa_plane_metrics *res)
 {
-    if (n <= 0) return;
+    if (n <= 0 || count <= 0) return;
+    const vqa_plane_desc &pd = planes[idx[0]];
     const int w = pd.width, h = pd.height;
-    const int ncb = (w - 10 + QOUT - 1) / QOUT, ns = (h - 10 + QS - 1) / QS;
+    const int qout = ssim_qout();
+    const int ncb = (w - 10 + qout - 1) / qout, ns = (h - 10 + QS - 1) / QS;
     const int bpp = ncb * ns;
-    hipLaunchKernelGGL(k_ssim_gauss, dim3(bpp, n), dim3(QT), 0, st, ref, dist, ref_frame_stride, dist_frame_stride,
-                       pd.offset, pd.row_stride, pd.pixel_step, w, h, ncb, ns, partials, plane_index, n_planes, res);
-    hipLaunchKernelGGL(k_ssim_finalize, dim3((n + 63) / 64), dim3(64), 0, st, partials, bpp, n,
-                       1.0 / ((double)(w - 10) * (double)(h - 10)), plane_index, n_planes, res);
+    plane_group g;
+    g.count = count;
+    for (int i = 0; i < 4; i++) { g.offset[i] = planes[idx[i < count ? i : 0]].offset; g.plane_index[i] = idx[i < count ? i : 0]; }
+#define LAUNCH_SSIM(NT, PF)                                                                                           \
+    hipLaunchKernelGGL((k_ssim_gauss<NT, PF>), dim3(bpp * count, n), dim3(NT), 0, st, ref, dist, ref_frame_stride,     \
+                       dist_frame_stride, g, pd.row_stride, pd.pixel_step, w, h, ncb, ns, partials,                   \
+                       partial_plane_stride, n_planes, res)
+    switch (ssim_variant()) {
+    case 1: LAUNCH_SSIM(256, 1); break;
+    case 2: LAUNCH_SSIM(256, 3); break;
+    case 3: LAUNCH_SSIM(256, 4); break;
+    case 4: LAUNCH_SSIM(128, 3); break;
+    default: LAUNCH_SSIM(256, 2); break;
+    }
+#undef LAUNCH_SSIM
+    for (int i = 0; i < count; i++)
+        hipLaunchKernelGGL(k_ssim_finalize, dim3((n + 63) / 64), dim3(64), 0, st,
+                           partials + (int64_t)idx[i] * partial_plane_stride, bpp, n,
+                           1.0 / ((double)(w - 10) * (double)(h - 10)), idx[i], n_planes, res);
 }
 
 // ---------------------------------------------------------------------------

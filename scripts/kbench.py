@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""A/B timing of kernel variants (env VQA_SSIM_VARIANT / VQA_DCT_VARIANT), one child process per
+variant so each gets a fresh library state.  usage: python scripts/kbench.py ssim 0 1 2 3 4 5 | dct 0 1 2"""
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def child(kind):
+    import numpy as np
+    import rtvqa_amd
+    from rtvqa_amd import _native as N, synth
+    from rtvqa_amd.engine import bgr_planes, gray_planes
+    from oracle import c_oracle as co, pipeline as pl
+    eng = rtvqa_amd.Engine(0)
+    # correctness on a small ragged case first
+    h, w = 140, 530
+    ref = synth.s_natural(2, h, w, seed=3)
+    dist = synth.distort(ref)
+    if kind == "ssim":
+        res = eng.quality(ref, dist, bgr_planes(h, w), N.SSIM_GAUSS)
+        for i in range(2):
+            sse, ssim = pl.frame_quality(ref[i], dist[i], bgr_planes(h, w), "gauss")
+            for p in range(3):
+                assert int(res[i, p]["sse"]) == sse[p]
+                assert abs(res[i, p]["ssim"] - ssim[p]) < 1e-5 * ssim[p], (res[i, p]["ssim"], ssim[p])
+    else:
+        rec = eng.complexity(dist[1:], prev0=dist[0], mask=N.M_DCT | N.M_TEMPORAL_DCT, dct_mode=N.DCT_BLOCK8)
+        e, l1, _ = co.dct8x8(co.bgr2gray(dist[0]), co.bgr2gray(dist[1]))
+        assert abs(rec[0]["dct_energy"] - e) < 1e-5 * e and abs(rec[0]["temporal_dct_l1"] - l1) < 1e-5 * l1
+    h, w, B = 1080, 1920, 64
+    ref = synth.s_natural(B + 1, h, w, seed=1)
+    dist = synth.distort(ref)
+    dr, dd = eng.upload(ref), eng.upload(dist)
+    eng.profile(True)
+    for rep in range(6):
+        if rep == 1:
+            eng.profile_read(reset=True)
+        if kind == "ssim":
+            eng.quality(dr.slice(1, B + 1), dd.slice(1, B + 1), bgr_planes(h, w), N.SSIM_GAUSS)
+        else:
+            eng.complexity(dd.slice(1, B + 1), prev0=dd.frame(0), mask=N.M_DCT | N.M_TEMPORAL_DCT, dct_mode=N.DCT_BLOCK8)
+    prof = eng.profile_read()
+    for k, (ms, cnt) in prof.items():
+        if k.startswith("k_ssim") or k.startswith("k_dct8"):
+            per = ms / cnt
+            npl = 3 if k.startswith("k_ssim") else 1
+            print("  %-16s %.4f ms/launch (%d frames x %d planes) = %.3f us/frame-plane  %.0f GB/s" %
+                  (k, per, B, npl, per * 1e3 / B / npl, 2 * h * w * B * npl / (per * 1e-3) / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--child":
+        child(sys.argv[2])
+    else:
+        kind = sys.argv[1]
+        for v in sys.argv[2:]:
+            env = dict(os.environ)
+            env["VQA_SSIM_VARIANT" if kind == "ssim" else "VQA_DCT_VARIANT"] = v
+            print("%s variant %s" % (kind, v), flush=True)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", kind], env=env, timeout=300)
+            if r.returncode:
+                print("  FAILED rc=%d" % r.returncode, flush=True)
