@@ -8,13 +8,19 @@
 //   halo (magnitude outside the image = 0, as OpenCV's zero-bordered buffer),
 //   NMS with the TG22 fixed-point sector test, double threshold.  Writes a
 //   1 B/px state map: 0 none, 1 weak candidate, 2 edge.
-// Stage 2 (k_canny_hyst): 8-connected hysteresis as an iterate-to-fixpoint over
-//   the same tiles: each workgroup relaxes its tile in LDS until nothing
-//   changes, then marks the neighbour tiles whose halo it changed.  Promotion
-//   is monotone (1 -> 2 only), so the fixpoint is unique and independent of
-//   scheduling: the count is bit-exact with the sequential stack walk.
+//   The result leaves the kernel as two BIT-PLANES (strong, weak), one u64 per
+//   64 pixels, assembled with __ballot: 2 x P/8 bytes instead of a P-byte map.
+// Stage 2 (k_canny_hyst_*): 8-connected hysteresis as an iterate-to-fixpoint on
+//   64x64-pixel tiles held ENTIRELY IN REGISTERS: lane r owns row r as a u64.
+//   One step = vertical neighbours by wave shuffles, 3-wide dilation by shifts,
+//   then a Kogge-Stone flood along the row (6 shift/and/or steps per direction),
+//   so a horizontal chain of any length is absorbed in ONE step.  Promotion is
+//   monotone (weak -> edge only), so the fixpoint is unique and independent of
+//   scheduling: the count is bit-exact with OpenCV's sequential stack walk.
+//   Tiles whose border changed enqueue their neighbours (dedup flag + atomic
+//   append); later rounds run over that compact list with a small fixed grid.
 //
-// Roofline: HBM, 3P bytes per frame (read gray, write state, read state).
+// Roofline: HBM, P + P/4 (+ P/4 per hysteresis pass over live tiles) bytes per frame.
 #include "vqa_dev.hpp"
 #include "vqa_kernels.hpp"
 #include "vqa_math.hpp"
@@ -28,10 +34,18 @@ constexpr int MW = TW + 2, MH = TH + 2;
 
 canny_geom canny_tiles(int h, int w) { return canny_geom{(w + TW - 1) / TW, (h + TH - 1) / TH}; }
 
-// tile_flags bit 0: tile holds weak pixels.
+// strong / weak: bit-planes in TILE-MAJOR order, [n][tiles_y][ww][64] u64 (ww = ceil(w/64), tiles_y =
+// ceil(h/64)): word r of tile (ty, tx) holds pixels (64 ty + r, 64 tx .. 64 tx + 63), bit k <-> column
+// 64 tx + k.  A hysteresis wave therefore reads its tile as 512 contiguous bytes.
+__host__ __device__ __forceinline__ int64_t bp_index(int f, int y, int tx, int ww, int tiles_y)
+{
+    return ((((int64_t)f * tiles_y + (y >> 6)) * ww + tx) << 6) + (y & 63);
+}
+
 __global__ __launch_bounds__(256) void k_canny_nms(const uint8_t *__restrict__ gray, int pitch, int64_t plane_stride,
-                                                   int h, int w, int low, int high, uint8_t *__restrict__ state,
-                                                   uint32_t *__restrict__ tile_flags,
+                                                   int h, int w, int low, int high,
+                                                   unsigned long long *__restrict__ strong,
+                                                   unsigned long long *__restrict__ weak, int ww,
                                                    vqa_frame_metrics *__restrict__ res)
 {
     __shared__ uint8_t sg[GR * GP];
@@ -88,26 +102,31 @@ __global__ __launch_bounds__(256) void k_canny_nms(const uint8_t *__restrict__ g
         sgxy[i] = (int)(((uint32_t)gy << 16) | ((uint32_t)gx & 0xffffu));
     }
     __syncthreads();
-    // ---- NMS + double threshold on the TH x TW interior
+    // ---- NMS + double threshold on the TH x TW interior; a wave owns one 64-pixel row per step,
+    //      so __ballot hands us that row's strong / weak words directly
     unsigned n_strong = 0, n_weak = 0;
-    uint8_t *st = state + (int64_t)f * plane_stride;
+    const int tiles_y = (h + 63) >> 6;
     for (int i = tid; i < TH * TW; i += 256) {
         const int ly = i / TW, lx = i - ly * TW;
         const int y = y0 + ly, x = x0 + lx;
+        int s = 0;
         if (y < h && x < w) {
             const uint16_t *c = smag + (ly + 1) * MW + (lx + 1);
             const int m = c[0];
             const int nb[8] = {c[-MW - 1], c[-MW], c[-MW + 1], c[-1], c[1], c[MW - 1], c[MW], c[MW + 1]};
             const int pk = sgxy[(ly + 1) * MW + (lx + 1)];
             const int gx = (int)(int16_t)(pk & 0xffff), gy = pk >> 16;
-            const int s = canny_classify(m, gx, gy, nb, low, high);
-            n_strong += (s == 2);
-            n_weak += (s == 1);
-            st[(int64_t)y * pitch + x] = (uint8_t)s;
+            s = canny_classify(m, gx, gy, nb, low, high);
+        }
+        const unsigned long long sm = __ballot(s == 2), wm = __ballot(s == 1);
+        if (lane_id() == 0 && y < h) {
+            const int64_t j = bp_index(f, y, blockIdx.x, ww, tiles_y);
+            strong[j] = sm;
+            weak[j] = wm;
+            n_strong += __popcll(sm);
+            n_weak += __popcll(wm);
         }
     }
-    n_strong = wave_sum(n_strong);
-    n_weak = wave_sum(n_weak);
     if (lane_id() == 0) {
         if (n_strong) atomicAdd(&s_cnt[0], n_strong);
         if (n_weak) atomicAdd(&s_cnt[1], n_weak);
@@ -116,97 +135,132 @@ __global__ __launch_bounds__(256) void k_canny_nms(const uint8_t *__restrict__ g
     if (tid == 0) {
         if (s_cnt[0]) atomicAdd(&res[f].edge_strong, s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&res[f].edge_weak, s_cnt[1]);
-        tile_flags[((int64_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s_cnt[1] ? 1u : 0u;
     }
 }
 
-// dirty bit layout for the 8 neighbours (dy, dx):
-//   bit0 (-1,-1) bit1 (-1,0) bit2 (-1,+1) bit3 (0,-1) bit4 (0,+1) bit5 (+1,-1) bit6 (+1,0) bit7 (+1,+1)
-constexpr int SW = TW + 2, SH = TH + 2;
+// ---------------------------------------------------------------------------
+// Hysteresis on bit-planes.  Tile = 64 columns x 64 rows = one wave; lane r <-> row r.
+// ---------------------------------------------------------------------------
+typedef unsigned long long u64;
 
-__global__ __launch_bounds__(256) void k_canny_hyst(uint8_t *__restrict__ state, int pitch, int64_t plane_stride,
-                                                    int h, int w, int round, const uint32_t *__restrict__ tile_flags,
-                                                    uint32_t *__restrict__ dirty_in, uint32_t *__restrict__ dirty_out,
-                                                    uint32_t *__restrict__ again, vqa_frame_metrics *__restrict__ res)
+__device__ __forceinline__ u64 shfl_up64(u64 v) { return __shfl_up(v, 1, 64); }
+__device__ __forceinline__ u64 shfl_dn64(u64 v) { return __shfl_down(v, 1, 64); }
+
+// occluded fill along a row: every run of `pro` cells touching a `gen` cell becomes gen
+__device__ __forceinline__ u64 flood_row(u64 gen, u64 pro)
 {
-    __shared__ uint8_t ss[SH * SW];
-    __shared__ unsigned s_flags[2]; // [0] neighbour-dirty mask, [1] promoted count
-    const int f = blockIdx.z;
-    const int64_t tile = ((int64_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    // wave-uniform activity test
-    bool active;
-    if (round == 0) {
-        active = tile_flags[tile] != 0;
-    } else {
-        active = dirty_in[tile] != 0;
+    u64 a = gen, m = pro;
+    a |= m & (a << 1);  m &= m << 1;
+    a |= m & (a << 2);  m &= m << 2;
+    a |= m & (a << 4);  m &= m << 4;
+    a |= m & (a << 8);  m &= m << 8;
+    a |= m & (a << 16); m &= m << 16;
+    a |= m & (a << 32);
+    u64 b = gen;
+    m = pro;
+    b |= m & (b >> 1);  m &= m >> 1;
+    b |= m & (b >> 2);  m &= m >> 2;
+    b |= m & (b >> 4);  m &= m >> 4;
+    b |= m & (b >> 8);  m &= m >> 8;
+    b |= m & (b >> 16); m &= m >> 16;
+    b |= m & (b >> 32);
+    return a | b;
+}
+
+__device__ __forceinline__ u64 dil3(u64 s, u64 l, u64 r) { return s | (s << 1) | (s >> 1) | l | (r << 63); }
+
+struct hyst_args {
+    u64 *strong;
+    const u64 *weak;
+    int h, ww, tiles_y;       // tiles_x == ww
+    unsigned *queued;         // per tile: already in the list being BUILT (flags of the list being consumed
+                              // live in a second array, so "queued for this round" never hides a re-enqueue)
+    unsigned *out_list;       // tile ids for the next round
+    unsigned *out_count;
+    vqa_frame_metrics *res;
+};
+
+// Relax one tile to its local fixpoint.  tile id = (f * tiles_y + ty) * ww + tx.  Whole wave calls this.
+__device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
+{
+    const int lane = lane_id();
+    const int tx = tile % A.ww;
+    const int ty = (tile / A.ww) % A.tiles_y;
+    const int f = tile / (A.ww * A.tiles_y);
+    const int y = ty * 64 + lane;
+    const bool in_img = y < A.h;
+    const int64_t idx = bp_index(f, in_img ? y : ty * 64, tx, A.ww, A.tiles_y);
+    const u64 s0 = in_img ? A.strong[idx] : 0ull;
+    const u64 w = in_img ? (A.weak[idx] & ~s0) : 0ull;
+    if (!__any(w != 0)) return; // nothing here can be promoted
+    // constant halo: the columns left / right of the tile and the rows above / below it
+    const u64 hl = (in_img && tx > 0) ? (A.strong[idx - 64] >> 63) : 0ull;
+    const u64 hr = (in_img && tx + 1 < A.ww) ? (A.strong[idx + 64] & 1ull) : 0ull;
+    u64 es = 0, el = 0, er = 0; // lane 0: row above the tile; lane 63: row below it
+    {
+        const int yy = lane == 0 ? ty * 64 - 1 : (lane == 63 ? ty * 64 + 64 : -1);
+        if (yy >= 0 && yy < A.h) {
+            const int64_t j = bp_index(f, yy, tx, A.ww, A.tiles_y);
+            es = A.strong[j];
+            if (tx > 0) el = A.strong[j - 64] >> 63;
+            if (tx + 1 < A.ww) er = A.strong[j + 64] & 1ull;
+        }
     }
-    __syncthreads(); // every thread has read dirty_in before it is cleared
-    if (round != 0 && threadIdx.x == 0 && active) dirty_in[tile] = 0;
-    if (!active) return;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    uint8_t *st = state + (int64_t)f * plane_stride;
-    const int tid = threadIdx.x;
-    if (tid < 2) s_flags[tid] = 0;
-    for (int i = tid; i < SH * SW; i += 256) {
-        const int ly = i / SW, lx = i - ly * SW;
-        const int y = y0 - 1 + ly, x = x0 - 1 + lx;
-        ss[i] = (y >= 0 && y < h && x >= 0 && x < w) ? st[(int64_t)y * pitch + x] : (uint8_t)0;
-    }
-    __syncthreads();
-    // thread owns 8 pixels: row ly = tid / 8 ... (TH*TW/256 = 8): column lx = tid % 64, rows (tid / 64) * 8 + k
-    const int lx = tid & 63, lyb = (tid >> 6) * 8;
-    uint32_t promoted_mask = 0;
+    u64 up_l = shfl_up64(hl), up_r = shfl_up64(hr), dn_l = shfl_dn64(hl), dn_r = shfl_dn64(hr);
+    if (lane == 0) { up_l = el; up_r = er; }
+    if (lane == 63) { dn_l = el; dn_r = er; }
+    const u64 F = s0 | w;
+    u64 s = s0;
     for (;;) {
-        int changed = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint8_t *c = ss + (lyb + k + 1) * SW + (lx + 1);
-            if (c[0] == 1) {
-                const int any2 = (c[-SW - 1] == 2) | (c[-SW] == 2) | (c[-SW + 1] == 2) | (c[-1] == 2) | (c[1] == 2) |
-                                 (c[SW - 1] == 2) | (c[SW] == 2) | (c[SW + 1] == 2);
-                if (any2) { c[0] = 2; changed = 1; promoted_mask |= 1u << k; }
-            }
-        }
-        if (!__syncthreads_or(changed)) break;
+        u64 up = shfl_up64(s), dn = shfl_dn64(s);
+        if (lane == 0) up = es;
+        if (lane == 63) dn = es;
+        const u64 d = dil3(up, up_l, up_r) | dil3(s, hl, hr) | dil3(dn, dn_l, dn_r);
+        const u64 x = flood_row(s | (w & d), F);
+        const bool changed = x != s;
+        s = x;
+        if (!__any(changed)) break;
     }
-    // write back promotions, count them, and find which neighbours saw their halo change
-    unsigned cnt = 0, nbr = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (promoted_mask & (1u << k)) {
-            const int ly = lyb + k;
-            st[(int64_t)(y0 + ly) * pitch + (x0 + lx)] = 2;
-            cnt++;
-            const bool top = ly == 0, bot = (ly == TH - 1), lef = lx == 0, rig = (lx == TW - 1);
-            if (top) nbr |= 1u << 1;
-            if (bot) nbr |= 1u << 6;
-            if (lef) nbr |= 1u << 3;
-            if (rig) nbr |= 1u << 4;
-            if (top && lef) nbr |= 1u << 0;
-            if (top && rig) nbr |= 1u << 2;
-            if (bot && lef) nbr |= 1u << 5;
-            if (bot && rig) nbr |= 1u << 7;
-        }
-    }
+    const u64 promoted = s & ~s0;
+    if (promoted) A.strong[idx] = s;
+    unsigned cnt = (unsigned)__popcll(promoted);
     cnt = wave_sum(cnt);
-    if (lane_id() == 0 && cnt) atomicAdd(&s_flags[1], cnt);
-    if (nbr) atomicOr(&s_flags[0], nbr);
-    __syncthreads();
-    if (tid == 0) {
-        if (s_flags[1]) atomicAdd(&res[f].edge_count, s_flags[1]);
-        const unsigned m = s_flags[0];
-        if (m) {
-            const int dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-            bool any = false;
-            for (int b = 0; b < 8; b++) {
-                if (!(m & (1u << b))) continue;
-                const int ty = (int)blockIdx.y + dys[b], tx = (int)blockIdx.x + dxs[b];
-                if (ty < 0 || ty >= (int)gridDim.y || tx < 0 || tx >= (int)gridDim.x) continue;
-                const int64_t t2 = ((int64_t)f * gridDim.y + ty) * gridDim.x + tx;
-                if (tile_flags[t2]) { dirty_out[t2] = 1; any = true; } // tiles without weak pixels cannot change
-            }
-            if (any) *again = 1;
+    // which neighbours saw their halo change
+    const bool L = __any((promoted & 1ull) != 0), R = __any((promoted >> 63) != 0);
+    const u64 p0 = __shfl(promoted, 0, 64), p63 = __shfl(promoted, 63, 64);
+    if (lane == 0) {
+        if (cnt) atomicAdd(&A.res[f].edge_count, cnt);
+        const bool U = p0 != 0, D = p63 != 0;
+        const bool nbr[8] = {(p0 & 1ull) != 0, U, (p0 >> 63) != 0, L, R, (p63 & 1ull) != 0, D, (p63 >> 63) != 0};
+        const int dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            if (!nbr[b]) continue;
+            const int ty2 = ty + dys[b], tx2 = tx + dxs[b];
+            if (ty2 < 0 || ty2 >= A.tiles_y || tx2 < 0 || tx2 >= A.ww) continue;
+            const unsigned t2 = (unsigned)((f * A.tiles_y + ty2) * A.ww + tx2);
+            if (atomicExch(&A.queued[t2], 1u) == 0u) A.out_list[atomicAdd(A.out_count, 1u)] = t2;
         }
+    }
+}
+
+// round 0: every tile.  grid = ceil(n_tiles / 4), block = 256 (4 independent waves)
+__global__ __launch_bounds__(256) void k_canny_hyst_all(hyst_args A, unsigned n_tiles)
+{
+    const unsigned tile = blockIdx.x * 4 + wave_id();
+    if (tile < n_tiles) relax_tile(A, tile);
+}
+
+// later rounds: the tiles some neighbour enqueued in the previous round
+__global__ __launch_bounds__(256) void k_canny_hyst_list(hyst_args A, const unsigned *__restrict__ in_list,
+                                                         const unsigned *__restrict__ in_count,
+                                                         unsigned *__restrict__ in_queued)
+{
+    const unsigned n = *in_count;
+    for (unsigned i = blockIdx.x * 4 + wave_id(); i < n; i += gridDim.x * 4) {
+        const unsigned tile = in_list[i];
+        if (lane_id() == 0) in_queued[tile] = 0; // this list is consumed; its flags are reused two rounds on
+        relax_tile(A, tile);
     }
 }
 
@@ -218,22 +272,43 @@ __global__ void k_canny_finish(int n, vqa_frame_metrics *__restrict__ res)
 }
 
 void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int n, int h, int w,
-                      int low, int high, uint8_t *state, uint32_t *tile_flags, vqa_frame_metrics *res)
+                      int low, int high, unsigned long long *strong, unsigned long long *weak,
+                      vqa_frame_metrics *res)
 {
     if (n <= 0) return;
     const canny_geom g = canny_tiles(h, w);
     hipLaunchKernelGGL(k_canny_nms, dim3(g.tiles_x, g.tiles_y, n), dim3(256), 0, st, gray, pitch, plane_stride, h, w,
-                       low, high, state, tile_flags, res);
+                       low, high, strong, weak, (w + 63) / 64, res);
 }
 
-void launch_canny_hyst(hipStream_t st, uint8_t *state, int pitch, int64_t plane_stride, int n, int h, int w,
-                       int round, uint32_t *tile_flags, uint32_t *dirty_in, uint32_t *dirty_out, uint32_t *again,
-                       vqa_frame_metrics *res)
+static hyst_args make_hyst_args(unsigned long long *strong, const unsigned long long *weak, int h, int w,
+                                unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res)
+{
+    hyst_args A;
+    A.strong = strong; A.weak = weak; A.h = h; A.ww = (w + 63) / 64; A.tiles_y = (h + 63) / 64;
+    A.queued = queued; A.out_list = out_list; A.out_count = out_count; A.res = res;
+    return A;
+}
+
+unsigned canny_hyst_tiles(int n, int h, int w) { return (unsigned)n * ((h + 63) / 64) * ((w + 63) / 64); }
+
+void launch_canny_hyst_all(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
+                           int w, unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res)
 {
     if (n <= 0) return;
-    const canny_geom g = canny_tiles(h, w);
-    hipLaunchKernelGGL(k_canny_hyst, dim3(g.tiles_x, g.tiles_y, n), dim3(256), 0, st, state, pitch, plane_stride, h, w,
-                       round, tile_flags, dirty_in, dirty_out, again, res);
+    const unsigned nt = canny_hyst_tiles(n, h, w);
+    hipLaunchKernelGGL(k_canny_hyst_all, dim3((nt + 3) / 4), dim3(256), 0, st,
+                       make_hyst_args(strong, weak, h, w, queued, out_list, out_count, res), nt);
+}
+
+void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
+                            int w, unsigned *in_queued, const unsigned *in_list, const unsigned *in_count,
+                            unsigned *out_queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_canny_hyst_list, dim3(512), dim3(256), 0, st,
+                       make_hyst_args(strong, weak, h, w, out_queued, out_list, out_count, res), in_list, in_count,
+                       in_queued);
 }
 
 void launch_canny_finish(hipStream_t st, int n, vqa_frame_metrics *res)

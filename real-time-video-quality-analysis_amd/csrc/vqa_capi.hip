@@ -465,43 +465,54 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     c->last_has_state = false;
     c->canny_rounds = 0;
     if (want_e) {
-        const canny_geom g = canny_tiles(ph, pw);
-        const size_t ntiles = (size_t)g.tiles_x * g.tiles_y * n;
-        rc = ensure(c, c->state, (size_t)plane_stride * n);
+        const int ww = (pw + 63) / 64;
+        const size_t words = (size_t)n * ((ph + 63) / 64) * ww * 64; // tile-major bit-planes
+        const unsigned ntiles = canny_hyst_tiles(n, ph, pw);
+        rc = ensure(c, c->state, sizeof(uint64_t) * words * 2); // strong plane, then weak plane
         if (rc) return rc;
-        rc = ensure(c, c->tile_flags, sizeof(uint32_t) * ntiles);
+        rc = ensure(c, c->tile_flags, sizeof(uint32_t) * ntiles * 2); // dedup flags, one array per work list
         if (rc) return rc;
-        rc = ensure(c, c->dirty0, sizeof(uint32_t) * ntiles);
+        rc = ensure(c, c->dirty0, sizeof(uint32_t) * ntiles);     // work list A
         if (rc) return rc;
-        rc = ensure(c, c->dirty1, sizeof(uint32_t) * ntiles);
+        rc = ensure(c, c->dirty1, sizeof(uint32_t) * ntiles);     // work list B
         if (rc) return rc;
-        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 64);
+        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 64);      // [0], [1]: list counters
         if (rc) return rc;
-        HIPCHK(c, hipMemsetAsync(c->dirty0.p, 0, sizeof(uint32_t) * ntiles, st));
-        HIPCHK(c, hipMemsetAsync(c->dirty1.p, 0, sizeof(uint32_t) * ntiles, st));
+        unsigned long long *strong = (unsigned long long *)c->state.p, *weak = strong + words;
+        unsigned *queued[2] = {(unsigned *)c->tile_flags.p, (unsigned *)c->tile_flags.p + ntiles};
+        unsigned *lists[2] = {(unsigned *)c->dirty0.p, (unsigned *)c->dirty1.p};
+        unsigned *counts = (unsigned *)c->again_dev.p;
+        HIPCHK(c, hipMemsetAsync(queued[0], 0, sizeof(uint32_t) * ntiles * 2, st));
+        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2, st));
         int lo = P.canny_low, hi = P.canny_high;
         if (lo > hi) { int t = lo; lo = hi; hi = t; }
         {
             prof_scope ps_(c, VQA_K_CANNY_NMS);
-            launch_canny_nms(st, pB, pp, plane_stride, n, ph, pw, lo, hi, (uint8_t *)c->state.p,
-                             (uint32_t *)c->tile_flags.p, res);
+            launch_canny_nms(st, pB, pp, plane_stride, n, ph, pw, lo, hi, strong, weak, res);
         }
-        // hysteresis to the fixpoint: rounds in groups of 3, one 4-byte readback per group
-        uint32_t *dirty[2] = {(uint32_t *)c->dirty0.p, (uint32_t *)c->dirty1.p};
-        uint32_t *again = (uint32_t *)c->again_dev.p;
+        // hysteresis to the fixpoint.  Round 0 relaxes every tile; round r > 0 relaxes the tiles that
+        // round r-1 enqueued into lists[r & 1].  One 4-byte readback per GROUP rounds.
         int round = 0;
-        const int GROUP = 3, MAX_ROUNDS = 1 << 20;
+        {
+            prof_scope ps_(c, VQA_K_CANNY_HYST);
+            launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], counts + 1, res);
+        }
+        round = 1;
+        const int GROUP = 4, MAX_ROUNDS = 1 << 20;
         for (;;) {
-            HIPCHK(c, hipMemsetAsync(again, 0, sizeof(uint32_t) * GROUP, st));
-            for (int k = 0; k < GROUP; k++, round++) {
-                // round r reads dirty[r & 1] (written by round r-1) and writes dirty[(r + 1) & 1]
+            {
                 prof_scope ps_(c, VQA_K_CANNY_HYST);
-                launch_canny_hyst(st, (uint8_t *)c->state.p, pp, plane_stride, n, ph, pw, round,
-                                  (uint32_t *)c->tile_flags.p, dirty[round & 1], dirty[(round + 1) & 1], again + k, res);
+                for (int k = 0; k < GROUP; k++, round++) {
+                    const int in = round & 1, out = in ^ 1;
+                    HIPCHK(c, hipMemsetAsync(counts + out, 0, sizeof(uint32_t), st));
+                    launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in, queued[out],
+                                           lists[out], counts + out, res);
+                }
             }
-            HIPCHK(c, hipMemcpyAsync(c->again_host, again, sizeof(uint32_t) * GROUP, hipMemcpyDeviceToHost, st));
+            // the list the next round would read
+            HIPCHK(c, hipMemcpyAsync(c->again_host, counts + (round & 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
-            if (!c->again_host[GROUP - 1]) break;
+            if (!c->again_host[0]) break;
             if (round >= MAX_ROUNDS) { c->last_err = "canny hysteresis did not converge"; return VQA_ERR_HIP; }
         }
         c->canny_rounds = (uint32_t)round;
@@ -670,16 +681,25 @@ int vqa_debug_read_plane(vqa_ctx *c, int which, int frame, uint8_t *dst, int dst
         }
     } else if (which == 2) {
         if (!c->last_has_state) return VQA_ERR_STATE;
-        h = c->last_ph; w = c->last_pw; pitch = c->last_pp;
-        src = (const uint8_t *)c->state.p + (int64_t)frame * h * pitch;
+        h = c->last_ph; w = c->last_pw;
+        if (dst_h != h || dst_w != w) return VQA_ERR_INVALID;
+        const int ww = (w + 63) / 64, ty_n = (h + 63) / 64;
+        std::vector<uint64_t> bits((size_t)ty_n * ww * 64);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(bits.data(), (const uint64_t *)c->state.p + (size_t)frame * bits.size(),
+                            sizeof(uint64_t) * bits.size(), hipMemcpyDeviceToHost));
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const uint64_t wd = bits[(((size_t)(y >> 6) * ww + (x >> 6)) << 6) + (y & 63)];
+                dst[(size_t)y * w + x] = ((wd >> (x & 63)) & 1ull) ? 255 : 0;
+            }
+        return VQA_OK;
     } else {
         return VQA_ERR_INVALID;
     }
     if (dst_h != h || dst_w != w) return VQA_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy2D(dst, (size_t)w, src, (size_t)pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost));
-    if (which == 2)
-        for (size_t i = 0; i < (size_t)h * w; i++) dst[i] = dst[i] == 2 ? 255 : 0;
     return VQA_OK;
 }
 

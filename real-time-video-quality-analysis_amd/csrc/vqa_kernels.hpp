@@ -32,13 +32,16 @@ struct canny_geom {
 };
 canny_geom canny_tiles(int h, int w);
 void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int n, int h, int w,
-                      int low, int high, uint8_t *state, uint32_t *tile_flags, vqa_frame_metrics *res);
-// one hysteresis round; round 0 visits every tile holding weak pixels, later
-// rounds only tiles marked dirty by a neighbour.  *again (device) is set when
-// any tile marked a neighbour dirty.
-void launch_canny_hyst(hipStream_t st, uint8_t *state, int pitch, int64_t plane_stride, int n, int h, int w,
-                       int round, uint32_t *tile_flags, uint32_t *dirty_in, uint32_t *dirty_out, uint32_t *again,
-                       vqa_frame_metrics *res);
+                      int low, int high, unsigned long long *strong, unsigned long long *weak,
+                      vqa_frame_metrics *res);
+// hysteresis on the strong/weak bit-planes: round 0 visits every 64x64 tile, later rounds the
+// tiles a neighbour enqueued (compact list + dedup flags); *out_count must be 0 at launch.
+unsigned canny_hyst_tiles(int n, int h, int w);
+void launch_canny_hyst_all(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
+                           int w, unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res);
+void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
+                            int w, unsigned *in_queued, const unsigned *in_list, const unsigned *in_count,
+                            unsigned *out_queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res);
 void launch_canny_finish(hipStream_t st, int n, vqa_frame_metrics *res);
 
 // k_sad.hip

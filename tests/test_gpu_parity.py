@@ -168,6 +168,19 @@ def test_canny_batch_of_mixed_frames(engine):
         assert int(rec[i]["edge_count"]) == co.canny(co.bgr2gray(fr[i]), 100, 200)[0], i
 
 
+def test_canny_1080p_many_rounds(engine):
+    """Low thresholds on natural content: long weak chains that cross many 64x64 tiles, so the
+    hysteresis needs many list rounds (and the enqueue/dedup protocol is exercised for real)."""
+    from rtvqa_amd import _native as N
+    fr = _frames("natural", 4, 1080, 1920, seed=21)
+    for low, high in ((30, 90), (100, 200)):
+        rec = engine.complexity(fr, mask=N.M_EDGE, canny=(low, high))
+        for i in range(4):
+            cnt, strong, weak = co.canny(co.bgr2gray(fr[i]), low, high)
+            assert (int(rec[i]["edge_strong"]), int(rec[i]["edge_weak"])) == (strong, weak)
+            assert int(rec[i]["edge_count"]) == cnt, (low, high, i)
+
+
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("h,w", [(96, 128), (100, 200), (64, 80), (48, 48), (10, 300), (160, 272)])
 @pytest.mark.parametrize("kind", ["natural", "noise"])
