@@ -211,8 +211,17 @@ def main():
         for name, (ms, _) in prof.items():
             kernels[name]["share_of_kernel_time"] = round(ms / tot, 4)
         dom = max((k for k in prof if k in alg_bytes), key=lambda k: prof[k][0])
+        # HBM traffic per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of THIS
+        # command (scripts/gpu_pmc.sh), corrected as the guide prescribes and committed under profiles/
+        traffic = None
+        pmc_path = os.path.join(REPO, "profiles", "round1_%s_pmc.json" % args.workload)
+        if os.path.exists(pmc_path) and args.ssim_mode == "gauss":
+            pmc = json.load(open(pmc_path))
+            for kname, ent in pmc["kernels"].items():
+                if kname.split("<")[0] == dom:
+                    traffic = int(ent["hbm_bytes"] * B / pmc["frames_per_launch"])
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kernels[dom]["frac_hbm"], "traffic": None,
+                "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "alg_bytes": alg_bytes[dom],
                 "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch; "
                         "k_ssim_gauss is VALU-bound by construction (DESIGN.md §5.5)"}
         line = {

@@ -102,7 +102,7 @@ typedef struct vqa_frame_metrics {
     uint32_t edge_strong;        /* pixels above `high` that survive NMS                    */
     uint32_t edge_weak;          /* NMS survivors in (low, high]                            */
     uint32_t has_prev;           /* 1 if a previous frame was available                     */
-    uint32_t pad_;
+    uint32_t hyst_steps;         /* diagnostics: relaxation steps summed over this frame's tiles       */
 } vqa_frame_metrics;
 
 /* One 8-bit plane inside a frame buffer (planar YUV plane, or one channel of

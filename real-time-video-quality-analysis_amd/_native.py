@@ -57,7 +57,7 @@ class VqaFrameMetrics(C.Structure):
                 ("edge_strong", C.c_uint32),
                 ("edge_weak", C.c_uint32),
                 ("has_prev", C.c_uint32),
-                ("pad_", C.c_uint32)]
+                ("hyst_steps", C.c_uint32)]
 
 
 class VqaPlaneDesc(C.Structure):

@@ -211,7 +211,9 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     if (lane == 63) { dn_l = el; dn_r = er; }
     const u64 F = s0 | w;
     u64 s = s0;
+    unsigned steps = 0;
     for (;;) {
+        steps++;
         u64 up = shfl_up64(s), dn = shfl_dn64(s);
         if (lane == 0) up = es;
         if (lane == 63) dn = es;
@@ -230,6 +232,7 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     const u64 p0 = __shfl(promoted, 0, 64), p63 = __shfl(promoted, 63, 64);
     if (lane == 0) {
         if (cnt) atomicAdd(&A.res[f].edge_count, cnt);
+        atomicAdd(&A.res[f].hyst_steps, steps);
         const bool U = p0 != 0, D = p63 != 0;
         const bool nbr[8] = {(p0 & 1ull) != 0, U, (p0 >> 63) != 0, L, R, (p63 & 1ull) != 0, D, (p63 >> 63) != 0};
         const int dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1};

@@ -33,7 +33,9 @@
 
 namespace vqa {
 
-constexpr int QS = 256;          // output rows per strip
+// output rows per strip: strips of at most ~1100 rows, balanced (1080p: one strip, 2160p: two)
+static inline int ssim_strips(int h) { return (h - 10 + 1099) / 1100; }
+static inline int ssim_strip_rows(int h) { const int ns = ssim_strips(h); return (h - 10 + ns - 1) / ns; }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -62,8 +64,10 @@ __device__ __forceinline__ float ssim_centered(float mx, float my, float sq, flo
 }
 
 // Up to 4 planes of identical geometry (e.g. the B, G, R channels of packed BGR24) are
-// handled by ONE launch: the plane index is the fastest-varying part of blockIdx.x, so the
-// workgroups that touch the same cache lines are dispatched together and share them in L2.
+// handled by ONE launch.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2),
+// so the blocks b, b+8, b+16 .. share an XCD: the plane index is therefore taken from (b / 8) % count,
+// which puts the workgroups that read the same cache lines (the channels of one tile) on the SAME
+// XCD, back to back (placement is a speed matter only).
 struct plane_group {
     int64_t offset[4];
     int plane_index[4];
@@ -75,10 +79,10 @@ struct plane_group {
 // accumulator file is 11 slots x 2 float2 = 44 VGPRs (80 VGPRs in all: 6 waves/SIMD).
 // PF = how many rows ahead the pixel loads run.
 // grid = (ncb * nstrips * group.count, n_frames)
-template <int QT, int PF>
+template <int QT, int PF, int HPF>
 __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dist,
                                                    int64_t ref_fs, int64_t dist_fs, plane_group g, int64_t row_stride,
-                                                   int step, int w, int h, int ncb, int nstrips,
+                                                   int step, int w, int h, int ncb, int nstrips, int QS,
                                                    double *__restrict__ partials, int64_t partial_plane_stride,
                                                    int n_planes, vqa_plane_metrics *__restrict__ res)
 {
@@ -88,7 +92,10 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
     __shared__ unsigned long long redu[4];
     const int f = blockIdx.y;
     const int t = threadIdx.x;
-    const int ch = blockIdx.x % g.count, tile = blockIdx.x / g.count;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int ch = seq % g.count, tile = (seq / g.count) * 8 + xcd;
+    const int bpp = ncb * nstrips;
+    if (tile >= bpp) return; // grid is padded to a multiple of 8 tiles
     const int cb = tile % ncb, sb = tile / ncb;
     const int xs = cb * QOUT, ys = sb * QS;
     const int xin = xs + t;
@@ -102,11 +109,10 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
     const uint8_t *rp = ref + (int64_t)f * ref_fs + base;
     const uint8_t *dp = dist + (int64_t)f * dist_fs + base;
 
-    f2 acc[2][11];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc[11]; // .xy = (E[x], E[y]) column sums, .zw = (E[x^2+y^2], E[xy]): one ds_write_b128 per row, no repacking
 #pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int s = 0; s < 11; s++) acc[m][s] = f2{0.f, 0.f};
+    for (int s = 0; s < 11; s++) acc[s] = f4{0.f, 0.f, 0.f, 0.f};
     float ssim_acc = 0.f;
     uint32_t sse_acc = 0;
 
@@ -143,25 +149,43 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
                 for (int k = 0; k < 11; k++) {
                     const int s = (p - k + 11) % 11;
                     if (k == 0) {
-                        acc[0][s] = gw(0) * xy;
-                        acc[1][s] = gw(0) * v1;
+                        acc[s].xy = gw(0) * xy;
+                        acc[s].zw = gw(0) * v1;
                     } else {
-                        acc[0][s] = __builtin_elementwise_fma(f2{gw(k), gw(k)}, xy, acc[0][s]);
-                        acc[1][s] = __builtin_elementwise_fma(f2{gw(k), gw(k)}, v1, acc[1][s]);
+                        acc[s].xy = __builtin_elementwise_fma(f2{gw(k), gw(k)}, xy, acc[s].xy);
+                        acc[s].zw = __builtin_elementwise_fma(f2{gw(k), gw(k)}, v1, acc[s].zw);
                     }
                 }
                 if (r >= 10) {
                     const int s = (p + 1) % 11; // slot of output row o = r - 10, now complete
                     const int buf = (r - 10) & 1;
-                    vb[buf][t] = make_float4(acc[0][s].x, acc[0][s].y, acc[1][s].x, acc[1][s].y);
+                    *(f4 *)&vb[buf][t] = acc[s];
                     __syncthreads();
                     if (out_c) {
                         f2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
+                        if (HPF == 0) {
 #pragma unroll
-                        for (int k = 0; k < 11; k++) {
-                            const float4 q = vb[buf][t + k];
-                            o0 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.x, q.y}, o0);
-                            o1 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.z, q.w}, o1);
+                            for (int k = 0; k < 11; k++) {
+                                const float4 q = vb[buf][t + k];
+                                o0 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.x, q.y}, o0);
+                                o1 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.z, q.w}, o1);
+                            }
+                        } else {
+                            // issue the LDS reads in groups of HPF before any arithmetic on them: the
+                            // default schedule keeps only ~2 reads in flight and eats LDS latency 5x per row
+                            float4 q[11];
+#pragma unroll
+                            for (int k0 = 0; k0 < 11; k0 += HPF) {
+#pragma unroll
+                                for (int k = k0; k < k0 + HPF && k < 11; k++) q[k] = vb[buf][t + k];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int k = k0; k < k0 + HPF && k < 11; k++) {
+                                    o0 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q[k].x, q[k].y}, o0);
+                                    o1 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q[k].z, q[k].w}, o1);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                         ssim_acc += ssim_centered(o0.x, o0.y, o1.x, o1.y);
                     }
@@ -173,7 +197,7 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
     const unsigned long long be = block_sum_u64((unsigned long long)sse_acc, redu);
     if (t == 0) {
         const int pidx = g.plane_index[ch];
-        partials[(int64_t)pidx * partial_plane_stride + (int64_t)f * (gridDim.x / g.count) + tile] = bs;
+        partials[(int64_t)pidx * partial_plane_stride + (int64_t)f * bpp + tile] = bs;
         if (be) atomicAdd((unsigned long long *)&res[(int64_t)f * n_planes + pidx].sse, be);
     }
 }
@@ -188,8 +212,8 @@ __global__ void k_ssim_finalize(const double *__restrict__ partials, int bpp, in
     res[(int64_t)f * n_planes + plane_index].ssim = s * inv_count;
 }
 
-// A/B knob for tuning runs (VQA_SSIM_VARIANT): 0 = {256 threads, prefetch 2} (default), 1 = {256, 1},
-// 2 = {256, 3}, 3 = {256, 4}, 4 = {128, 3}
+// A/B knob for tuning runs (VQA_SSIM_VARIANT): {threads, pixel prefetch rows, LDS reads in flight}:
+// 0 = {256,2,compiler's}, 1 = {256,2,11}, 2 = {256,2,6}, 3 = {256,2,4}, 4 = {128,2,compiler's}
 static int ssim_variant()
 {
     static int v = -1;
@@ -206,7 +230,7 @@ int ssim_gauss_blocks(int h, int w)
 {
     if (h < 11 || w < 11) return 0;
     const int qout = ssim_qout();
-    const int ncb = (w - 10 + qout - 1) / qout, ns = (h - 10 + QS - 1) / QS;
+    const int ncb = (w - 10 + qout - 1) / qout, ns = ssim_strips(h);
     return ncb * ns;
 }
 
@@ -219,21 +243,21 @@ void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dis
     const vqa_plane_desc &pd = planes[idx[0]];
     const int w = pd.width, h = pd.height;
     const int qout = ssim_qout();
-    const int ncb = (w - 10 + qout - 1) / qout, ns = (h - 10 + QS - 1) / QS;
+    const int ncb = (w - 10 + qout - 1) / qout, ns = ssim_strips(h), QS = ssim_strip_rows(h);
     const int bpp = ncb * ns;
     plane_group g;
     g.count = count;
     for (int i = 0; i < 4; i++) { g.offset[i] = planes[idx[i < count ? i : 0]].offset; g.plane_index[i] = idx[i < count ? i : 0]; }
-#define LAUNCH_SSIM(NT, PF)                                                                                           \
-    hipLaunchKernelGGL((k_ssim_gauss<NT, PF>), dim3(bpp * count, n), dim3(NT), 0, st, ref, dist, ref_frame_stride,     \
-                       dist_frame_stride, g, pd.row_stride, pd.pixel_step, w, h, ncb, ns, partials,                   \
+#define LAUNCH_SSIM(NT, PF, HPF)                                                                                      \
+    hipLaunchKernelGGL((k_ssim_gauss<NT, PF, HPF>), dim3((bpp + 7) / 8 * 8 * count, n), dim3(NT), 0, st, ref, dist, ref_frame_stride,\
+                       dist_frame_stride, g, pd.row_stride, pd.pixel_step, w, h, ncb, ns, QS, partials,               \
                        partial_plane_stride, n_planes, res)
     switch (ssim_variant()) {
-    case 1: LAUNCH_SSIM(256, 1); break;
-    case 2: LAUNCH_SSIM(256, 3); break;
-    case 3: LAUNCH_SSIM(256, 4); break;
-    case 4: LAUNCH_SSIM(128, 3); break;
-    default: LAUNCH_SSIM(256, 2); break;
+    case 1: LAUNCH_SSIM(256, 2, 11); break;
+    case 2: LAUNCH_SSIM(256, 2, 6); break;
+    case 3: LAUNCH_SSIM(256, 2, 4); break;
+    case 4: LAUNCH_SSIM(128, 2, 0); break;
+    default: LAUNCH_SSIM(256, 2, 0); break;
     }
 #undef LAUNCH_SSIM
     for (int i = 0; i < count; i++)

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Fold the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of scripts/gpu_pmc.sh into
+profiles/<tag>_pmc.json: per kernel, mean counter values per launch and the HBM bytes after the
+guide's gfx950 correction (FETCH_SIZE is in KiB and counts 128-B requests as 64 B: double it;
+WRITE_SIZE in KiB is exact).  usage: pmc_summarize.py <tag> <frames_per_launch>"""
+import collections, csv, glob, json, os, sys
+tag, frames = sys.argv[1], int(sys.argv[2])
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {"tag": tag, "frames_per_launch": frames, "unit": "bytes per launch",
+       "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md §HBM)", "kernels": {}}
+vals = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (tag, ctr), "*", "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("vqa::", "")
+        agg[name].append(float(r["Counter_Value"]))
+    vals[ctr] = agg
+for name in vals["FETCH_SIZE"]:
+    if name.startswith("__amd") or "finalize" in name or "finish" in name:
+        continue
+    fs, ws = vals["FETCH_SIZE"][name], vals["WRITE_SIZE"].get(name, [0.0])
+    big = max(fs)
+    fsel = [v for v in fs if v > 0.5 * big]  # drop the 1-frame prev0 launches
+    wbig = max(ws)
+    wsel = [v for v in ws if v > 0.5 * wbig] or [0.0]
+    fetch, write = sum(fsel) / len(fsel), sum(wsel) / len(wsel)
+    out["kernels"][name] = {"FETCH_SIZE_KiB": round(fetch, 1), "WRITE_SIZE_KiB": round(write, 1), "launches": len(fsel),
+                            "hbm_bytes": int(2 * fetch * 1024 + write * 1024)}
+path = os.path.join(root, "profiles", "%s_pmc.json" % tag)
+json.dump(out, open(path, "w"), indent=1)
+print(json.dumps(out, indent=1))
