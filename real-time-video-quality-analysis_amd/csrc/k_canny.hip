@@ -146,28 +146,60 @@ typedef unsigned long long u64;
 __device__ __forceinline__ u64 shfl_up64(u64 v) { return __shfl_up(v, 1, 64); }
 __device__ __forceinline__ u64 shfl_dn64(u64 v) { return __shfl_down(v, 1, 64); }
 
-// occluded fill along a row: every run of `pro` cells touching a `gen` cell becomes gen
-__device__ __forceinline__ u64 flood_row(u64 gen, u64 pro)
+// 64-bit rows as two 32-bit halves: gfx950 issues 64-bit shifts at a fraction of the 32-bit rate, so the
+// shift/and/or ladder is written on halves with v_alignbit_b32 carrying bits across the middle.
+struct row64 {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ row64 to_row(u64 v) { return row64{(uint32_t)v, (uint32_t)(v >> 32)}; }
+__device__ __forceinline__ u64 to_u64(row64 r) { return (u64)r.lo | ((u64)r.hi << 32); }
+template <int K>
+__device__ __forceinline__ row64 shl(row64 a)
 {
-    u64 a = gen, m = pro;
-    a |= m & (a << 1);  m &= m << 1;
-    a |= m & (a << 2);  m &= m << 2;
-    a |= m & (a << 4);  m &= m << 4;
-    a |= m & (a << 8);  m &= m << 8;
-    a |= m & (a << 16); m &= m << 16;
-    a |= m & (a << 32);
-    u64 b = gen;
+    if (K == 32) return row64{0u, a.lo};
+    return row64{a.lo << K, __builtin_amdgcn_alignbit(a.hi, a.lo, 32 - K)}; // (hi:lo) >> (32-K), low word
+}
+template <int K>
+__device__ __forceinline__ row64 shr(row64 a)
+{
+    if (K == 32) return row64{a.hi, 0u};
+    return row64{__builtin_amdgcn_alignbit(a.hi, a.lo, K), a.hi >> K};
+}
+__device__ __forceinline__ row64 operator&(row64 a, row64 b) { return row64{a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ row64 operator|(row64 a, row64 b) { return row64{a.lo | b.lo, a.hi | b.hi}; }
+// a | (m & t): one v_and_or_b32 per half
+__device__ __forceinline__ row64 and_or(row64 m, row64 t, row64 a) { return row64{(m.lo & t.lo) | a.lo, (m.hi & t.hi) | a.hi}; }
+
+// occluded fill along a row: every run of `pro` cells touching a `gen` cell becomes gen
+__device__ __forceinline__ row64 flood_row(row64 gen, row64 pro)
+{
+    row64 a = gen, m = pro;
+    a = and_or(m, shl<1>(a), a);  m = m & shl<1>(m);
+    a = and_or(m, shl<2>(a), a);  m = m & shl<2>(m);
+    a = and_or(m, shl<4>(a), a);  m = m & shl<4>(m);
+    a = and_or(m, shl<8>(a), a);  m = m & shl<8>(m);
+    a = and_or(m, shl<16>(a), a); m = m & shl<16>(m);
+    a = and_or(m, shl<32>(a), a);
+    row64 b = gen;
     m = pro;
-    b |= m & (b >> 1);  m &= m >> 1;
-    b |= m & (b >> 2);  m &= m >> 2;
-    b |= m & (b >> 4);  m &= m >> 4;
-    b |= m & (b >> 8);  m &= m >> 8;
-    b |= m & (b >> 16); m &= m >> 16;
-    b |= m & (b >> 32);
+    b = and_or(m, shr<1>(b), b);  m = m & shr<1>(m);
+    b = and_or(m, shr<2>(b), b);  m = m & shr<2>(m);
+    b = and_or(m, shr<4>(b), b);  m = m & shr<4>(m);
+    b = and_or(m, shr<8>(b), b);  m = m & shr<8>(m);
+    b = and_or(m, shr<16>(b), b); m = m & shr<16>(m);
+    b = and_or(m, shr<32>(b), b);
     return a | b;
 }
 
-__device__ __forceinline__ u64 dil3(u64 s, u64 l, u64 r) { return s | (s << 1) | (s >> 1) | l | (r << 63); }
+// 3-wide horizontal dilation of a row plus the tile's left (bit 0) and right (bit 63) halo bits
+__device__ __forceinline__ row64 dil3(row64 s, uint32_t l, uint32_t r)
+{
+    const row64 sl = shl<1>(s), sr = shr<1>(s);
+    return row64{s.lo | sl.lo | sr.lo | l, s.hi | sl.hi | sr.hi | (r << 31)};
+}
+
+__device__ __forceinline__ row64 shfl_up_row(row64 v) { return row64{(uint32_t)__shfl_up((int)v.lo, 1, 64), (uint32_t)__shfl_up((int)v.hi, 1, 64)}; }
+__device__ __forceinline__ row64 shfl_dn_row(row64 v) { return row64{(uint32_t)__shfl_down((int)v.lo, 1, 64), (uint32_t)__shfl_down((int)v.hi, 1, 64)}; }
 
 struct hyst_args {
     u64 *strong;
@@ -206,23 +238,26 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
             if (tx + 1 < A.ww) er = A.strong[j + 64] & 1ull;
         }
     }
-    u64 up_l = shfl_up64(hl), up_r = shfl_up64(hr), dn_l = shfl_dn64(hl), dn_r = shfl_dn64(hr);
-    if (lane == 0) { up_l = el; up_r = er; }
-    if (lane == 63) { dn_l = el; dn_r = er; }
-    const u64 F = s0 | w;
-    u64 s = s0;
+    const uint32_t hl32 = (uint32_t)hl, hr32 = (uint32_t)hr;
+    uint32_t up_l = (uint32_t)__shfl_up((int)hl32, 1, 64), up_r = (uint32_t)__shfl_up((int)hr32, 1, 64);
+    uint32_t dn_l = (uint32_t)__shfl_down((int)hl32, 1, 64), dn_r = (uint32_t)__shfl_down((int)hr32, 1, 64);
+    if (lane == 0) { up_l = (uint32_t)el; up_r = (uint32_t)er; }
+    if (lane == 63) { dn_l = (uint32_t)el; dn_r = (uint32_t)er; }
+    const row64 wr = to_row(w), F = to_row(s0 | w), esr = to_row(es);
+    row64 sr = to_row(s0);
     unsigned steps = 0;
     for (;;) {
         steps++;
-        u64 up = shfl_up64(s), dn = shfl_dn64(s);
-        if (lane == 0) up = es;
-        if (lane == 63) dn = es;
-        const u64 d = dil3(up, up_l, up_r) | dil3(s, hl, hr) | dil3(dn, dn_l, dn_r);
-        const u64 x = flood_row(s | (w & d), F);
-        const bool changed = x != s;
-        s = x;
-        if (!__any(changed)) break;
+        row64 up = shfl_up_row(sr), dn = shfl_dn_row(sr);
+        if (lane == 0) up = esr;
+        if (lane == 63) dn = esr;
+        const row64 d = dil3(up, up_l, up_r) | dil3(sr, hl32, hr32) | dil3(dn, dn_l, dn_r);
+        // weak cells touching an edge cell that are not edges yet; none anywhere in the tile => fixpoint
+        const row64 cand = row64{wr.lo & d.lo & ~sr.lo, wr.hi & d.hi & ~sr.hi};
+        if (!__any((cand.lo | cand.hi) != 0u)) break;
+        sr = flood_row(sr | cand, F);
     }
+    const u64 s = to_u64(sr);
     const u64 promoted = s & ~s0;
     if (promoted) A.strong[idx] = s;
     unsigned cnt = (unsigned)__popcll(promoted);

@@ -30,21 +30,23 @@ __global__ __launch_bounds__(256) void k_bgr2gray_hist(const uint8_t *__restrict
                                                        uint8_t *__restrict__ gray, int gp, int64_t plane_stride,
                                                        vqa_frame_metrics *__restrict__ res, uint32_t flags)
 {
-    __shared__ uint32_t lh[4][4][256]; // [wave][gray,b,g,r][bin]
+    // [gray,b,g,r][bin][copy]: 8 copies of every bin, chosen by lane & 7 and INTERLEAVED so that the copies
+    // of one bin sit in 8 different LDS banks.  On smooth content most lanes of a wave hit the same few
+    // bins; this turns a 64-way same-address serialisation into at most 8-way.
+    __shared__ uint32_t lh[4 * 256 * 8];
     __shared__ unsigned long long red[4];
     const int f = blockIdx.y;
     const bool hg = (flags & F_GRAY_HIST) && res, hc = (flags & F_COLOR_HIST) && res;
     const bool any_hist = hg || hc;
-    uint32_t *lhf = &lh[0][0][0];
     if (any_hist) {
-        for (int i = threadIdx.x; i < 4 * 4 * 256; i += 256) lhf[i] = 0;
+        for (int i = threadIdx.x; i < 4 * 256 * 8; i += 256) lh[i] = 0;
         __syncthreads();
     }
+    const unsigned cp = threadIdx.x & 7u;
     const uint8_t *src = bgr + (int64_t)f * frame_stride;
     uint8_t *dst = gray + (int64_t)f * plane_stride;
     const int cpr = (w + 15) >> 4;
     const int total = h * cpr;
-    const unsigned wv = wave_id();
     unsigned long long s2 = 0;
     for (int c = blockIdx.x * 256 + threadIdx.x; c < total; c += gridDim.x * 256) {
         const int y = c / cpr;
@@ -71,11 +73,11 @@ __global__ __launch_bounds__(256) void k_bgr2gray_hist(const uint8_t *__restrict
             g[i] = bgr2gray_u8(b, gg, r);
             if (VEC || i < npx) {
                 sq += g[i] * g[i];
-                if (hg) atomicAdd(&lh[wv][0][g[i]], 1u);
+                if (hg) atomicAdd(&lh[(g[i] << 3) | cp], 1u);
                 if (hc) {
-                    atomicAdd(&lh[wv][1][b], 1u);
-                    atomicAdd(&lh[wv][2][gg], 1u);
-                    atomicAdd(&lh[wv][3][r], 1u);
+                    atomicAdd(&lh[((256u + b) << 3) | cp], 1u);
+                    atomicAdd(&lh[((512u + gg) << 3) | cp], 1u);
+                    atomicAdd(&lh[((768u + r) << 3) | cp], 1u);
                 }
             }
         }
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(256) void k_bgr2gray_hist(const uint8_t *__restrict
     if (any_hist) {
         __syncthreads();
         for (int i = threadIdx.x; i < 4 * 256; i += 256) {
-            const uint32_t v = lhf[i] + lhf[1024 + i] + lhf[2048 + i] + lhf[3072 + i];
+            const uint4 c0 = *(const uint4 *)&lh[i * 8], c1 = *(const uint4 *)&lh[i * 8 + 4];
+            const uint32_t v = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
             if (v) {
                 const int which = i >> 8, bin = i & 255;
                 uint32_t *gdst = which == 0 ? &res[f].hist_gray[bin] : &res[f].hist_bgr[which - 1][bin];
