@@ -207,8 +207,8 @@ struct hyst_args {
     int h, ww, tiles_y;       // tiles_x == ww
     unsigned *queued;         // per tile: already in the list being BUILT (flags of the list being consumed
                               // live in a second array, so "queued for this round" never hides a re-enqueue)
-    unsigned *out_list;       // tile ids for the next round
-    unsigned *out_count;
+    unsigned *out_list;       // tile ids for the next round, one segment of tiles_y*ww entries PER FRAME
+    unsigned *out_count;      // one append counter per frame (a single global counter serialises ~1e5 atomics)
     vqa_frame_metrics *res;
 };
 
@@ -225,17 +225,21 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     const u64 s0 = in_img ? A.strong[idx] : 0ull;
     const u64 w = in_img ? (A.weak[idx] & ~s0) : 0ull;
     if (!__any(w != 0)) return; // nothing here can be promoted
-    // constant halo: the columns left / right of the tile and the rows above / below it
-    const u64 hl = (in_img && tx > 0) ? (A.strong[idx - 64] >> 63) : 0ull;
-    const u64 hr = (in_img && tx + 1 < A.ww) ? (A.strong[idx + 64] & 1ull) : 0ull;
-    u64 es = 0, el = 0, er = 0; // lane 0: row above the tile; lane 63: row below it
+    // constant halo: the columns left / right of the tile and the rows above / below it.  Besides the
+    // halo's edge bits (h*, e*) we keep its CANDIDATE bits (weak and not yet edge: c*, ec*): a neighbour is
+    // only worth re-visiting if one of its candidates touches a pixel this tile promotes.
+    u64 hl = 0, hr = 0, cl = 0, cr = 0;
+    if (in_img && tx > 0) { const u64 sL = A.strong[idx - 64]; hl = sL >> 63; cl = (A.weak[idx - 64] & ~sL) >> 63; }
+    if (in_img && tx + 1 < A.ww) { const u64 sR = A.strong[idx + 64]; hr = sR & 1ull; cr = (A.weak[idx + 64] & ~sR) & 1ull; }
+    u64 es = 0, el = 0, er = 0, ecs = 0, ecl = 0, ecr = 0; // lane 0: row above the tile; lane 63: row below it
     {
         const int yy = lane == 0 ? ty * 64 - 1 : (lane == 63 ? ty * 64 + 64 : -1);
         if (yy >= 0 && yy < A.h) {
             const int64_t j = bp_index(f, yy, tx, A.ww, A.tiles_y);
             es = A.strong[j];
-            if (tx > 0) el = A.strong[j - 64] >> 63;
-            if (tx + 1 < A.ww) er = A.strong[j + 64] & 1ull;
+            ecs = A.weak[j] & ~es;
+            if (tx > 0) { const u64 t = A.strong[j - 64]; el = t >> 63; ecl = (A.weak[j - 64] & ~t) >> 63; }
+            if (tx + 1 < A.ww) { const u64 t = A.strong[j + 64]; er = t & 1ull; ecr = (A.weak[j + 64] & ~t) & 1ull; }
         }
     }
     const uint32_t hl32 = (uint32_t)hl, hr32 = (uint32_t)hr;
@@ -262,14 +266,21 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     if (promoted) A.strong[idx] = s;
     unsigned cnt = (unsigned)__popcll(promoted);
     cnt = wave_sum(cnt);
-    // which neighbours saw their halo change
-    const bool L = __any((promoted & 1ull) != 0), R = __any((promoted >> 63) != 0);
-    const u64 p0 = __shfl(promoted, 0, 64), p63 = __shfl(promoted, 63, 64);
+    // Which neighbours must be re-visited: those holding a candidate pixel 8-adjacent to a promoted one.
+    // (Candidate bits may be stale by one promotion: stale edge bits only ever make this test MORE
+    // inclusive, never less, because edges only grow.)
+    const u64 pb0 = promoted & 1ull, pb63 = promoted >> 63;
+    u64 n0 = pb0 | (u64)__shfl_up((int)pb0, 1, 64) * (lane > 0) | (u64)__shfl_down((int)pb0, 1, 64) * (lane < 63);
+    u64 n63 = pb63 | (u64)__shfl_up((int)pb63, 1, 64) * (lane > 0) | (u64)__shfl_down((int)pb63, 1, 64) * (lane < 63);
+    const bool L = __any((cl & n0) != 0), R = __any((cr & n63) != 0);
+    const u64 pd = promoted | (promoted << 1) | (promoted >> 1); // promoted row, dilated along x
+    const bool Uf = __any(lane == 0 && (ecs & pd) != 0), Df = __any(lane == 63 && (ecs & pd) != 0);
+    const bool ULf = __any(lane == 0 && (ecl & pb0) != 0), URf = __any(lane == 0 && (ecr & pb63) != 0);
+    const bool DLf = __any(lane == 63 && (ecl & pb0) != 0), DRf = __any(lane == 63 && (ecr & pb63) != 0);
     if (lane == 0) {
         if (cnt) atomicAdd(&A.res[f].edge_count, cnt);
         atomicAdd(&A.res[f].hyst_steps, steps);
-        const bool U = p0 != 0, D = p63 != 0;
-        const bool nbr[8] = {(p0 & 1ull) != 0, U, (p0 >> 63) != 0, L, R, (p63 & 1ull) != 0, D, (p63 >> 63) != 0};
+        const bool nbr[8] = {ULf, Uf, URf, L, R, DLf, Df, DRf};
         const int dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -277,7 +288,8 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
             const int ty2 = ty + dys[b], tx2 = tx + dxs[b];
             if (ty2 < 0 || ty2 >= A.tiles_y || tx2 < 0 || tx2 >= A.ww) continue;
             const unsigned t2 = (unsigned)((f * A.tiles_y + ty2) * A.ww + tx2);
-            if (atomicExch(&A.queued[t2], 1u) == 0u) A.out_list[atomicAdd(A.out_count, 1u)] = t2;
+            if (atomicExch(&A.queued[t2], 1u) == 0u)
+                A.out_list[(unsigned)f * (unsigned)(A.tiles_y * A.ww) + atomicAdd(&A.out_count[f], 1u)] = t2;
         }
     }
 }
@@ -294,9 +306,10 @@ __global__ __launch_bounds__(256) void k_canny_hyst_list(hyst_args A, const unsi
                                                          const unsigned *__restrict__ in_count,
                                                          unsigned *__restrict__ in_queued)
 {
-    const unsigned n = *in_count;
+    const unsigned f = blockIdx.y, tpf = (unsigned)(A.tiles_y * A.ww);
+    const unsigned n = in_count[f];
     for (unsigned i = blockIdx.x * 4 + wave_id(); i < n; i += gridDim.x * 4) {
-        const unsigned tile = in_list[i];
+        const unsigned tile = in_list[f * tpf + i];
         if (lane_id() == 0) in_queued[tile] = 0; // this list is consumed; its flags are reused two rounds on
         relax_tile(A, tile);
     }
@@ -344,7 +357,7 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
                             unsigned *out_queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_canny_hyst_list, dim3(512), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_canny_hyst_list, dim3(8, n), dim3(256), 0, st,
                        make_hyst_args(strong, weak, h, w, out_queued, out_list, out_count, res), in_list, in_count,
                        in_queued);
 }

@@ -46,6 +46,7 @@ struct vqa_ctx {
     void *res_host = nullptr; size_t res_host_cap = 0;
     void *qres_host = nullptr; size_t qres_host_cap = 0;
     uint32_t *again_host = nullptr;
+    void *again_host_v = nullptr; size_t again_host_cap = 0;
 
     std::map<std::tuple<int, int, int, int>, resize_tabs> tabs;
     std::map<int, float *> dct_mats;
@@ -282,6 +283,7 @@ int vqa_destroy(vqa_ctx *c)
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->qres_host) (void)hipHostFree(c->qres_host);
     if (c->again_host) (void)hipHostFree(c->again_host);
+    if (c->again_host_v) (void)hipHostFree(c->again_host_v);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return VQA_OK;
@@ -476,14 +478,16 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         if (rc) return rc;
         rc = ensure(c, c->dirty1, sizeof(uint32_t) * ntiles);     // work list B
         if (rc) return rc;
-        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 64);      // [0], [1]: list counters
+        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 2 * n);   // per-frame append counters of the two lists
+        if (rc) return rc;
+        rc = ensure_pinned(c, c->again_host_v, c->again_host_cap, sizeof(uint32_t) * n);
         if (rc) return rc;
         unsigned long long *strong = (unsigned long long *)c->state.p, *weak = strong + words;
         unsigned *queued[2] = {(unsigned *)c->tile_flags.p, (unsigned *)c->tile_flags.p + ntiles};
         unsigned *lists[2] = {(unsigned *)c->dirty0.p, (unsigned *)c->dirty1.p};
         unsigned *counts = (unsigned *)c->again_dev.p;
         HIPCHK(c, hipMemsetAsync(queued[0], 0, sizeof(uint32_t) * ntiles * 2, st));
-        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2, st));
+        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * n, st));
         int lo = P.canny_low, hi = P.canny_high;
         if (lo > hi) { int t = lo; lo = hi; hi = t; }
         {
@@ -495,7 +499,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         int round = 0;
         {
             prof_scope ps_(c, VQA_K_CANNY_HYST);
-            launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], counts + 1, res);
+            launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], counts + n, res);
         }
         round = 1;
         const int GROUP = 4, MAX_ROUNDS = 1 << 20;
@@ -504,15 +508,18 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
                 prof_scope ps_(c, VQA_K_CANNY_HYST);
                 for (int k = 0; k < GROUP; k++, round++) {
                     const int in = round & 1, out = in ^ 1;
-                    HIPCHK(c, hipMemsetAsync(counts + out, 0, sizeof(uint32_t), st));
-                    launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in, queued[out],
-                                           lists[out], counts + out, res);
+                    HIPCHK(c, hipMemsetAsync(counts + out * n, 0, sizeof(uint32_t) * n, st));
+                    launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in * n,
+                                           queued[out], lists[out], counts + out * n, res);
                 }
             }
             // the list the next round would read
-            HIPCHK(c, hipMemcpyAsync(c->again_host, counts + (round & 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(c->again_host_v, counts + (round & 1) * n, sizeof(uint32_t) * n,
+                                     hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
-            if (!c->again_host[0]) break;
+            uint32_t pending = 0;
+            for (int i = 0; i < n; i++) pending |= ((const uint32_t *)c->again_host_v)[i];
+            if (!pending) break;
             if (round >= MAX_ROUNDS) { c->last_err = "canny hysteresis did not converge"; return VQA_ERR_HIP; }
         }
         c->canny_rounds = (uint32_t)round;

@@ -304,6 +304,27 @@ def test_full_size_1080p_parity_and_properties(engine):
     assert (same["sse"] == 0).all() and np.allclose(same["ssim"], 1.0, atol=1e-6)
 
 
+def test_full_size_2160p_parity(engine):
+    """BASELINE.json configs[3]'s frame size (3840x2160), one frame pair against the oracle."""
+    from rtvqa_amd import _native as N
+    from rtvqa_amd import synth
+    from rtvqa_amd.engine import gray_planes
+    h, w = 2160, 3840
+    fr = _frames("natural", 2, h, w, seed=15)
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+    g, gp = co.bgr2gray(fr[1]), co.bgr2gray(fr[0])
+    assert (rec[0]["hist_gray"] == co.hist_u8(g)).all()
+    assert (rec[0]["hist_bgr"][2] == co.hist_u8(fr[1], offset=2, step=3)).all()
+    assert int(rec[0]["edge_count"]) == co.canny(g, 100, 200)[0]
+    nb, sad, hist = co.block_sad(gp, g, 7)
+    assert int(rec[0]["sad_sum"]) == sad and (rec[0]["mv_d2_hist"] == hist).all() and rec[0]["sad_blocks"] == nb
+    e, l1, _ = co.dct8x8(gp, g)
+    assert _rel(rec[0]["dct_energy"], e) < RTOL and _rel(rec[0]["temporal_dct_l1"], l1) < RTOL
+    gd = synth.distort(g[None])
+    _check_quality(engine, g[None], gd, gray_planes(h, w), "gauss")
+    _check_quality(engine, g[None], gd, gray_planes(h, w), "ffmpeg")
+
+
 def test_argument_errors(engine):
     from rtvqa_amd import _native as N
     fr = np.zeros((1, 32, 32, 3), np.uint8)
