@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frame pairs for the CPU baseline (0 = skip)")
     ap.add_argument("--ssim-mode", default="gauss", choices=["gauss", "ffmpeg"])
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="1: one stream; 2: quality on its own stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,7 +133,10 @@ def main():
     from rtvqa_amd import synth
     from rtvqa_amd.engine import DeviceBuffer, DeviceFrames, bgr_planes
 
+    # two contexts = two HIP streams on the same device: the VALU-bound SSIM launch overlaps the
+    # memory/latency-bound complexity kernels and the host round-trips of the Canny fixpoint
     eng = rtvqa_amd.Engine(local_rank)
+    eng_q = rtvqa_amd.Engine(local_rank) if args.streams == 2 else eng
 
     # ---- synthetic streams, generated in chunks and made resident in HBM before timing
     fbytes = h * w * 3
@@ -155,14 +159,15 @@ def main():
     smode = N.SSIM_GAUSS if args.ssim_mode == "gauss" else N.SSIM_FFMPEG
 
     def step():
-        eng.quality_submit(ref_b, dist_b, planes, smode)
+        eng_q.quality_submit(ref_b, dist_b, planes, smode)
         eng.complexity_submit(dist_b, prev0, mask, params)
-        q = eng.quality_wait()
+        q = eng_q.quality_wait()
         c = eng.complexity_wait()
         return q, c
 
     def fence():
         eng.sync()
+        eng_q.sync()
         torch.cuda.synchronize()
         if dist_on:
             td.barrier()
@@ -172,6 +177,9 @@ def main():
         step()
     eng.profile(True)
     eng.profile_read(reset=True)
+    if eng_q is not eng:
+        eng_q.profile(True)
+        eng_q.profile_read(reset=True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -180,6 +188,9 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read(reset=True)
     eng.profile(False)
+    if eng_q is not eng:
+        prof.update(eng_q.profile_read(reset=True))  # NOTE: with 2 streams a launch's event time includes sharing the GPU
+        eng_q.profile(False)
 
     # ---- max over ranks, and the one scalar all-reduce the path has (pooled metrics)
     if dist_on:
@@ -230,7 +241,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->f32 (SSE/bins/SAD exact int)",
             "data": "synthetic (synth.s_natural v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
                     % synth.GENERATOR_VERSION,
-            "config": {"workload": wl["name"], "id": args.workload, "frames_per_step_per_gpu": B,
+            "config": {"workload": wl["name"], "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams,
                        "resident": "HBM", "ssim_mode": args.ssim_mode, "parallelism": "1 stream/GPU x%d" % world},
             "roofline": roof, "kernels": kernels,
         }
@@ -240,6 +251,8 @@ def main():
     if dist_on:
         td.barrier()
         td.destroy_process_group()
+    if eng_q is not eng:
+        eng_q.close()
     eng.close()
 
 

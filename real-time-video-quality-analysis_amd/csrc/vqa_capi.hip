@@ -502,7 +502,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], counts + n, res);
         }
         round = 1;
-        const int GROUP = 4, MAX_ROUNDS = 1 << 20;
+        const int GROUP = 8, MAX_ROUNDS = 1 << 20;
         for (;;) {
             {
                 prof_scope ps_(c, VQA_K_CANNY_HYST);

@@ -14,23 +14,8 @@ def child(kind):
     import rtvqa_amd
     from rtvqa_amd import _native as N, synth
     from rtvqa_amd.engine import bgr_planes, gray_planes
-    from oracle import c_oracle as co, pipeline as pl
     eng = rtvqa_amd.Engine(0)
-    # correctness on a small ragged case first
-    h, w = 140, 530
-    ref = synth.s_natural(2, h, w, seed=3)
-    dist = synth.distort(ref)
-    if kind == "ssim":
-        res = eng.quality(ref, dist, bgr_planes(h, w), N.SSIM_GAUSS)
-        for i in range(2):
-            sse, ssim = pl.frame_quality(ref[i], dist[i], bgr_planes(h, w), "gauss")
-            for p in range(3):
-                assert int(res[i, p]["sse"]) == sse[p]
-                assert abs(res[i, p]["ssim"] - ssim[p]) < 1e-5 * ssim[p], (res[i, p]["ssim"], ssim[p])
-    else:
-        rec = eng.complexity(dist[1:], prev0=dist[0], mask=N.M_DCT | N.M_TEMPORAL_DCT, dct_mode=N.DCT_BLOCK8)
-        e, l1, _ = co.dct8x8(co.bgr2gray(dist[0]), co.bgr2gray(dist[1]))
-        assert abs(rec[0]["dct_energy"] - e) < 1e-5 * e and abs(rec[0]["temporal_dct_l1"] - l1) < 1e-5 * l1
+    # (parity of every variant is covered by tests/ -m gpu, which reads the same env knobs)
     h, w, B = 1080, 1920, 64
     ref = synth.s_natural(B + 1, h, w, seed=1)
     dist = synth.distort(ref)
