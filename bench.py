@@ -97,7 +97,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frame pairs for the CPU baseline (0 = skip)")
     ap.add_argument("--ssim-mode", default="gauss", choices=["gauss", "ffmpeg"])
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2], help="1: one stream; 2: quality on its own stream")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="1 (default): one stream, clean per-kernel event times; 2: quality kernels on a second stream (+4-8%% fps, event times of overlapped kernels are inflated)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the rank logic)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,11 +125,17 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # VQA_BENCH_DEVICE pins every rank to one device: only for rehearsing the N > 1 logic on a 1-GPU box (gloo)
+    device = int(os.environ.get("VQA_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device)
     dist_on = world > 1
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
     if dist_on:
         import torch.distributed as td
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            td.init_process_group("gloo", rank=rank, world_size=world)
 
     import rtvqa_amd
     from rtvqa_amd import _native as N
@@ -135,8 +144,8 @@ def main():
 
     # two contexts = two HIP streams on the same device: the VALU-bound SSIM launch overlaps the
     # memory/latency-bound complexity kernels and the host round-trips of the Canny fixpoint
-    eng = rtvqa_amd.Engine(local_rank)
-    eng_q = rtvqa_amd.Engine(local_rank) if args.streams == 2 else eng
+    eng = rtvqa_amd.Engine(device)
+    eng_q = rtvqa_amd.Engine(device) if args.streams == 2 else eng
 
     # ---- synthetic streams, generated in chunks and made resident in HBM before timing
     fbytes = h * w * 3
@@ -194,11 +203,11 @@ def main():
 
     # ---- max over ranks, and the one scalar all-reduce the path has (pooled metrics)
     if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
         pooled = torch.tensor([float(q["ssim"].mean()), float(c["dct_energy"].mean()), float(B)],
-                              dtype=torch.float64, device="cuda")
+                              dtype=torch.float64, device=red_dev)
         td.all_reduce(pooled, op=td.ReduceOp.SUM)  # RCCL over xGMI: 24 bytes, latency-bound
     frames_total = B * args.steps * world
     value = frames_total / dt
