@@ -216,7 +216,7 @@ def main():
         P = h * w
         alg_bytes = {  # algorithmic HBM bytes per profiled launch group (SURVEY.md §8d x frames per launch)
             "k_ssim_gauss": 2 * P * B * len(planes),  # one launch covers the B, G, R planes (2P each)
-            "k_ssim_ffmpeg": 2 * P * B, "k_dct8": 2 * P * B,
+            "k_ssim_ffmpeg": 2 * P * B * len(planes), "k_dct8": 2 * P * B,
             "k_bgr2gray_hist": 4 * P * (B + 1), "k_canny_nms": 2 * P * B, "k_block_sad": 2 * P * B,
         }
         kernels = {}

@@ -333,6 +333,104 @@ __global__ __launch_bounds__(64) void k_ssim_ffmpeg(const uint8_t *__restrict__ 
     }
 }
 
+// Fast path of the same filter: dword loads and v_dot4_u32_u8.  One load of 4 pixels feeds five dot
+// products (s1 = <a,1>, s2 = <b,1>, ss = <a,a> + <b,b>, s12 = <a,b>), the squared error falls out as
+// ss - 2 s12, and for packed BGR24 the three channels are de-interleaved in registers (2 v_perm_b32
+// each) so ONE pass over the bytes serves all three planes: 6P bytes per frame pair, HBM-bound.
+// NCH = 1: planar plane, pixel_step 1.  NCH = 3: planes at byte offsets +0,+1,+2 with pixel_step 3.
+template <int NCH>
+__global__ __launch_bounds__(64) void k_ssim_ffmpeg_fast(const uint8_t *__restrict__ ref,
+                                                         const uint8_t *__restrict__ dist, int64_t ref_fs,
+                                                         int64_t dist_fs, int64_t offset, int64_t row_stride, int w,
+                                                         int h, int ncw, int nstrips, double *__restrict__ partials,
+                                                         int64_t partial_plane_stride, int plane_index0, int n_planes,
+                                                         vqa_plane_metrics *__restrict__ res)
+{
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int cw = blockIdx.x % ncw, sb = blockIdx.x / ncw;
+    const int bw = w >> 2, bh = h >> 2;
+    const int bx = cw * 63 + lane;
+    const int by0 = sb * FS_ROWS;
+    const int by_end = min(by0 + FS_ROWS + 1, bh);
+    const bool last_cw = cw == ncw - 1, last_sb = sb == nstrips - 1;
+    const bool have = bx < bw;
+    const uint8_t *rb = ref + (int64_t)f * ref_fs + offset + (int64_t)(have ? bx : 0) * 4 * NCH;
+    const uint8_t *db = dist + (int64_t)f * dist_fs + offset + (int64_t)(have ? bx : 0) * 4 * NCH;
+    int p1[NCH], p2[NCH], pss[NCH], p12[NCH];
+    double ssim_acc[NCH];
+    unsigned long long sse_acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) { p1[c] = p2[c] = pss[c] = p12[c] = 0; ssim_acc[c] = 0; sse_acc[c] = 0; }
+    for (int by = by0; by < by_end; by++) {
+        uint32_t s1[NCH], s2[NCH], ss[NCH], s12[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) s1[c] = s2[c] = ss[c] = s12[c] = 0;
+        struct __attribute__((aligned(4))) wvec { uint32_t v[NCH]; }; // NCH = 3 -> one global_load_dwordx3
+        uint32_t ra[4][NCH], da[4][NCH];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            wvec rv, dv;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) rv.v[c] = dv.v[c] = 0u;
+            if (have) {
+                rv = *(const wvec *)(rb + (int64_t)(by * 4 + y) * row_stride);
+                dv = *(const wvec *)(db + (int64_t)(by * 4 + y) * row_stride);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { ra[y][c] = rv.v[c]; da[y][c] = dv.v[c]; }
+        }
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            uint32_t a[NCH], b[NCH];
+            if (NCH == 3) {
+                // 12 bytes B0 G0 R0 B1 .. R3 -> (B0 B1 B2 B3), (G0 G1 G2 G3), (R0 R1 R2 R3)
+                const uint32_t *wa = ra[y], *wb = da[y];
+                a[0] = __builtin_amdgcn_perm(wa[2], __builtin_amdgcn_perm(wa[1], wa[0], 0x0c060300u), 0x05020100u);
+                a[1 % NCH] = __builtin_amdgcn_perm(wa[2], __builtin_amdgcn_perm(wa[1], wa[0], 0x0c070401u), 0x06020100u);
+                a[2 % NCH] = __builtin_amdgcn_perm(wa[2], __builtin_amdgcn_perm(wa[1], wa[0], 0x0c0c0502u), 0x07040100u);
+                b[0] = __builtin_amdgcn_perm(wb[2], __builtin_amdgcn_perm(wb[1], wb[0], 0x0c060300u), 0x05020100u);
+                b[1 % NCH] = __builtin_amdgcn_perm(wb[2], __builtin_amdgcn_perm(wb[1], wb[0], 0x0c070401u), 0x06020100u);
+                b[2 % NCH] = __builtin_amdgcn_perm(wb[2], __builtin_amdgcn_perm(wb[1], wb[0], 0x0c0c0502u), 0x07040100u);
+            } else {
+                a[0] = ra[y][0];
+                b[0] = da[y][0];
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                s1[c] = __builtin_amdgcn_udot4(a[c], 0x01010101u, s1[c], false);
+                s2[c] = __builtin_amdgcn_udot4(b[c], 0x01010101u, s2[c], false);
+                ss[c] = __builtin_amdgcn_udot4(a[c], a[c], ss[c], false);
+                ss[c] = __builtin_amdgcn_udot4(b[c], b[c], ss[c], false);
+                s12[c] = __builtin_amdgcn_udot4(a[c], b[c], s12[c], false);
+            }
+        }
+        const bool own = have && (last_cw || lane < 63) && (last_sb || by < by0 + FS_ROWS);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            if (own) sse_acc[c] += (unsigned long long)(ss[c] - 2u * s12[c]);
+            if (by > by0) {
+                const int v1 = p1[c] + (int)s1[c], v2 = p2[c] + (int)s2[c], vss = pss[c] + (int)ss[c],
+                          v12 = p12[c] + (int)s12[c];
+                const int n1 = __shfl_down(v1, 1, 64), n2 = __shfl_down(v2, 1, 64);
+                const int nss = __shfl_down(vss, 1, 64), n12 = __shfl_down(v12, 1, 64);
+                if (lane < 63 && bx + 1 < bw)
+                    ssim_acc[c] += (double)ssim_ffmpeg_end1(v1 + n1, v2 + n2, vss + nss, v12 + n12);
+            }
+            p1[c] = (int)s1[c]; p2[c] = (int)s2[c]; pss[c] = (int)ss[c]; p12[c] = (int)s12[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const double sa = wave_sum(ssim_acc[c]);
+        const unsigned long long se = wave_sum(sse_acc[c]);
+        if (lane == 0) {
+            partials[(int64_t)(plane_index0 + c) * partial_plane_stride + (int64_t)f * gridDim.x + blockIdx.x] = sa;
+            if (se) atomicAdd((unsigned long long *)&res[(int64_t)f * n_planes + plane_index0 + c].sse, se);
+        }
+    }
+}
+
 // SSE of the rows/columns that no 4x4 block covers (ragged right/bottom edges);
 // one thread per frame is plenty: at most 3 rows + 3 columns.
 __global__ void k_sse_ragged(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dist, int64_t ref_fs,
@@ -363,23 +461,54 @@ int ssim_ffmpeg_blocks(int h, int w)
     return ncw * ns;
 }
 
-void launch_quality_ffmpeg(hipStream_t st, const uint8_t *ref, const uint8_t *dist, int n, int64_t ref_frame_stride,
-                           int64_t dist_frame_stride, const vqa_plane_desc &pd, int plane_index, int n_planes,
-                           double *partials, vqa_plane_metrics *res)
+static bool aligned4(const void *p, int64_t a, int64_t b, int64_t c, int64_t d)
 {
-    if (n <= 0) return;
+    return (((uintptr_t)p | (uint64_t)a | (uint64_t)b | (uint64_t)c | (uint64_t)d) & 3u) == 0;
+}
+
+// planes[idx[0..count)] share geometry.  count == 3 with pixel_step 3 and byte offsets o, o+1, o+2 (packed
+// BGR24) takes the fused three-channel path; pixel_step 1 takes the planar fast path; anything else the
+// generic byte kernel.  partials: [n_planes][partial_plane_stride].
+void launch_quality_ffmpeg(hipStream_t st, const uint8_t *ref, const uint8_t *dist, int n, int64_t ref_frame_stride,
+                           int64_t dist_frame_stride, const vqa_plane_desc *planes, const int *idx, int count,
+                           int n_planes, double *partials, int64_t partial_plane_stride, vqa_plane_metrics *res)
+{
+    if (n <= 0 || count <= 0) return;
+    const vqa_plane_desc &pd = planes[idx[0]];
     const int w = pd.width, h = pd.height;
     const int bw = w >> 2, bh = h >> 2;
     const int ncw = (bw - 1 + 62) / 63, ns = (bh - 1 + FS_ROWS - 1) / FS_ROWS;
     const int bpp = ncw * ns;
-    hipLaunchKernelGGL(k_ssim_ffmpeg, dim3(bpp, n), dim3(64), 0, st, ref, dist, ref_frame_stride, dist_frame_stride,
-                       pd.offset, pd.row_stride, pd.pixel_step, w, h, ncw, ns, partials, plane_index, n_planes, res);
-    if ((w & 3) || (h & 3))
-        hipLaunchKernelGGL(k_sse_ragged, dim3((n + 63) / 64), dim3(64), 0, st, ref, dist, ref_frame_stride,
-                           dist_frame_stride, pd.offset, pd.row_stride, pd.pixel_step, w, h, n, plane_index, n_planes,
-                           res);
-    hipLaunchKernelGGL(k_ssim_finalize, dim3((n + 63) / 64), dim3(64), 0, st, partials, bpp, n,
-                       1.0 / ((double)(bh - 1) * (double)(bw - 1)), plane_index, n_planes, res);
+    const bool al = aligned4(ref, (int64_t)(uintptr_t)dist, ref_frame_stride, dist_frame_stride, pd.row_stride);
+    const bool fused3 = al && count == 3 && pd.pixel_step == 3 && (pd.offset & 3) == 0 &&
+                        planes[idx[1]].offset == pd.offset + 1 && planes[idx[2]].offset == pd.offset + 2 &&
+                        idx[1] == idx[0] + 1 && idx[2] == idx[0] + 2;
+    if (fused3) {
+        hipLaunchKernelGGL(k_ssim_ffmpeg_fast<3>, dim3(bpp, n), dim3(64), 0, st, ref, dist, ref_frame_stride,
+                           dist_frame_stride, pd.offset, pd.row_stride, w, h, ncw, ns, partials, partial_plane_stride,
+                           idx[0], n_planes, res);
+    } else {
+        for (int i = 0; i < count; i++) {
+            const vqa_plane_desc &q = planes[idx[i]];
+            if (al && q.pixel_step == 1 && (q.offset & 3) == 0)
+                hipLaunchKernelGGL(k_ssim_ffmpeg_fast<1>, dim3(bpp, n), dim3(64), 0, st, ref, dist, ref_frame_stride,
+                                   dist_frame_stride, q.offset, q.row_stride, w, h, ncw, ns, partials,
+                                   partial_plane_stride, idx[i], n_planes, res);
+            else
+                hipLaunchKernelGGL(k_ssim_ffmpeg, dim3(bpp, n), dim3(64), 0, st, ref, dist, ref_frame_stride,
+                                   dist_frame_stride, q.offset, q.row_stride, q.pixel_step, w, h, ncw, ns,
+                                   partials + (int64_t)idx[i] * partial_plane_stride, idx[i], n_planes, res);
+        }
+    }
+    for (int i = 0; i < count; i++) {
+        const vqa_plane_desc &q = planes[idx[i]];
+        if ((w & 3) || (h & 3))
+            hipLaunchKernelGGL(k_sse_ragged, dim3((n + 63) / 64), dim3(64), 0, st, ref, dist, ref_frame_stride,
+                               dist_frame_stride, q.offset, q.row_stride, q.pixel_step, w, h, n, idx[i], n_planes, res);
+        hipLaunchKernelGGL(k_ssim_finalize, dim3((n + 63) / 64), dim3(64), 0, st,
+                           partials + (int64_t)idx[i] * partial_plane_stride, bpp, n,
+                           1.0 / ((double)(bh - 1) * (double)(bw - 1)), idx[i], n_planes, res);
+    }
 }
 
 } // namespace vqa

@@ -595,8 +595,8 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
     HIPCHK(c, hipMemsetAsync(c->qres_dev.p, 0, sizeof(vqa_plane_metrics) * nent, st));
     vqa_plane_metrics *res = (vqa_plane_metrics *)c->qres_dev.p;
     const int64_t pstride = (int64_t)maxblocks * n;
-    if (ssim_mode == VQA_SSIM_GAUSS) {
-        // planes of identical geometry (B,G,R of packed BGR; U,V of 4:2:0) go out as one launch
+    {
+        // planes of identical geometry (B,G,R of packed BGR; U,V of 4:2:0) go out as one group
         bool done[4] = {false, false, false, false};
         for (int p = 0; p < n_planes; p++) {
             if (done[p]) continue;
@@ -608,15 +608,13 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
                     done[q] = true;
                 }
             }
-            prof_scope ps_(c, VQA_K_SSIM_GAUSS);
-            launch_quality_gauss(st, dref, ddist, n, ref_fs, dist_fs, planes, idx, cnt, n_planes,
-                                 (double *)c->qpartials.p, pstride, res);
-        }
-    } else {
-        for (int p = 0; p < n_planes; p++) {
-            prof_scope ps_(c, VQA_K_SSIM_FFMPEG);
-            launch_quality_ffmpeg(st, dref, ddist, n, ref_fs, dist_fs, planes[p], p, n_planes,
-                                  (double *)c->qpartials.p + (size_t)p * pstride, res);
+            prof_scope ps_(c, ssim_mode == VQA_SSIM_GAUSS ? VQA_K_SSIM_GAUSS : VQA_K_SSIM_FFMPEG);
+            if (ssim_mode == VQA_SSIM_GAUSS)
+                launch_quality_gauss(st, dref, ddist, n, ref_fs, dist_fs, planes, idx, cnt, n_planes,
+                                     (double *)c->qpartials.p, pstride, res);
+            else
+                launch_quality_ffmpeg(st, dref, ddist, n, ref_fs, dist_fs, planes, idx, cnt, n_planes,
+                                      (double *)c->qpartials.p, pstride, res);
         }
     }
     HIPCHK(c, hipGetLastError());

@@ -54,8 +54,8 @@ void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dis
                           int64_t dist_frame_stride, const vqa_plane_desc *planes, const int *idx, int count,
                           int n_planes, double *partials, int64_t partial_plane_stride, vqa_plane_metrics *res);
 void launch_quality_ffmpeg(hipStream_t st, const uint8_t *ref, const uint8_t *dist, int n, int64_t ref_frame_stride,
-                           int64_t dist_frame_stride, const vqa_plane_desc &pd, int plane_index, int n_planes,
-                           double *partials, vqa_plane_metrics *res);
+                           int64_t dist_frame_stride, const vqa_plane_desc *planes, const int *idx, int count,
+                           int n_planes, double *partials, int64_t partial_plane_stride, vqa_plane_metrics *res);
 int ssim_ffmpeg_blocks(int h, int w);
 
 } // namespace vqa

@@ -1,0 +1,55 @@
+"""PCIe-inclusive rate of workload c2: frames start in PINNED HOST memory every step (H2D inside the
+submit call), ping-ponged over two contexts so copy and compute overlap.  Quoted in DESIGN.md §6; it is
+never bench.py's `value`."""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, rtvqa_amd
+from rtvqa_amd import _native as N, synth
+from rtvqa_amd.engine import bgr_planes
+
+h, w, B, steps = 1080, 1920, 64, 8
+engs = [rtvqa_amd.Engine(0), rtvqa_amd.Engine(0)]
+fb = h * w * 3
+
+
+def pinned(eng, n):
+    p = C.c_void_p()
+    N.check(eng.lib.vqa_alloc_pinned(eng.ctx, n, C.byref(p)), "pinned", eng.ctx)
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,))
+
+
+ref = synth.s_natural(B + 1, h, w, seed=3)
+bufs = []
+for e in engs:
+    r = pinned(e, fb * (B + 1)).reshape(B + 1, h, w, 3); d = pinned(e, fb * (B + 1)).reshape(B + 1, h, w, 3)
+    r[:] = ref; d[:] = synth.distort(ref)
+    bufs.append((r, d))
+planes = bgr_planes(h, w)
+params = engs[0].make_params(dct_mode=N.DCT_BLOCK8)
+
+
+def submit(i):
+    e = engs[i & 1]; r, d = bufs[i & 1]
+    e.quality_submit(r[1:], d[1:], planes, N.SSIM_GAUSS)
+    e.complexity_submit(d[1:], d[0], N.M_DCT | N.M_TEMPORAL_DCT, params)
+
+
+def wait(i):
+    e = engs[i & 1]
+    return e.quality_wait(), e.complexity_wait()
+
+
+for mode in ("serial", "overlapped"):
+    submit(0); wait(0)
+    t0 = time.perf_counter()
+    if mode == "serial":
+        for i in range(steps):
+            submit(0); wait(0)
+    else:
+        submit(0)
+        for i in range(1, steps):
+            submit(i); wait(i - 1)
+        wait(steps - 1)
+    dt = time.perf_counter() - t0
+    gb = 2 * fb * (B + 1) * steps / 1e9
+    print("%s: %.0f frames/s PCIe-inclusive, %.1f GB/s H2D" % (mode, B * steps / dt, gb / dt))
