@@ -277,6 +277,27 @@ def test_device_resident_equals_host_and_batching(engine):
             assert (one[0][name] == host[i][name]).all(), (i, name)
 
 
+def test_torch_tensor_frames_zero_copy(engine):
+    """PyTorch-ROCm is plumbing: a CUDA(HIP) uint8 tensor's data_ptr() goes straight into the C ABI
+    (one HIP runtime in the process), and gives the same records as host frames."""
+    import torch
+    from rtvqa_amd import _native as N
+    from rtvqa_amd.engine import DeviceFrames, bgr_planes
+    from rtvqa_amd import synth
+    fr = _frames("natural", 4, 96, 160, seed=17)
+    dist = synth.distort(fr)
+    t_ref, t_dist = torch.from_numpy(fr).cuda(), torch.from_numpy(dist).cuda()
+    torch.cuda.synchronize()
+    d_ref, d_dist = DeviceFrames.from_torch(t_ref), DeviceFrames.from_torch(t_dist)
+    host = engine.complexity(dist[1:], prev0=dist[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+    dev = engine.complexity(d_dist.slice(1, 4), prev0=d_dist.frame(0), mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+    for name in host.dtype.names:
+        assert (host[name] == dev[name]).all(), name
+    qh = engine.quality(fr, dist, bgr_planes(96, 160), N.SSIM_GAUSS)
+    qd = engine.quality(d_ref, d_dist, bgr_planes(96, 160), N.SSIM_GAUSS)
+    assert (qh["sse"] == qd["sse"]).all() and (qh["ssim"] == qd["ssim"]).all()
+
+
 def test_full_size_1080p_parity_and_properties(engine):
     """BASELINE.json's frame size: two 1080p frames against the oracle, plus size-independent
     properties (Parseval, bin totals, identical-pair invariants)."""
