@@ -102,6 +102,9 @@ class Engine:
 
     def close(self):
         if getattr(self, "ctx", None):
+            for p in getattr(self, "_pinned", []):
+                self.lib.vqa_free_pinned(self.ctx, p)
+            self._pinned = []
             self.lib.vqa_destroy(self.ctx)
             self.ctx = None
 
@@ -126,6 +129,17 @@ class Engine:
         N.check(self.lib.vqa_sync(self.ctx), "vqa_sync", self.ctx)
         ch = arr.shape[3] if arr.ndim == 4 else 1
         return DeviceFrames(buf.ptr, arr.shape[0], arr.shape[1], arr.shape[2], owner=buf, channels=ch)
+
+    def alloc_pinned(self, shape, dtype=np.uint8):
+        """A NumPy array backed by page-locked host memory (hipHostMalloc): H2D from it is a true async DMA.
+        The memory lives until the engine is closed."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        N.check(self.lib.vqa_alloc_pinned(self.ctx, max(nbytes, 1), C.byref(p)), "vqa_alloc_pinned", self.ctx)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))
+        return raw[:nbytes].view(dtype).reshape(shape)
 
     def sync(self):
         N.check(self.lib.vqa_sync(self.ctx), "vqa_sync", self.ctx)

@@ -87,11 +87,26 @@ def ssim_stats_line(n, ssim_row, sizes, comps):
     return "".join(parts)
 
 
+def _open_quality_stream(src, layout, height, width):
+    """-> (frames, layout, height, width).  .y4m paths select the yuv420p layout by themselves."""
+    if isinstance(src, str) and src.endswith(".y4m"):
+        from .frames import read_y4m
+        arr, h, w, _fps = read_y4m(src)
+        return arr, "yuv420p", h, w
+    if layout == "bgr24":
+        return _open_frames(src), layout, height, width
+    return src, layout, height, width
+
+
 def run_ffmpeg_metrics(reference_video, distorted_video, psnr_log, ssim_log, vmaf_log, vmaf_model_path=None,
                        layout="bgr24", ssim_mode="gauss", height=None, width=None):
-    """video_processing.py:270-297 — PSNR and SSIM between two streams, one stats line per frame."""
-    ref = _open_frames(reference_video) if layout == "bgr24" else reference_video
-    dist = _open_frames(distorted_video) if layout == "bgr24" else distorted_video
+    """video_processing.py:270-297 — PSNR and SSIM between two streams, one stats line per frame.
+    Streams: [N,H,W,3] BGR arrays / .npy (components r,g,b as FFmpeg labels RGB input), planar yuv420p
+    arrays with height/width, or .y4m files (components y,u,v — what FFmpeg sees for an H.264 clip)."""
+    ref, layout, height, width = _open_quality_stream(reference_video, layout, height, width)
+    dist, layout_d, _, _ = _open_quality_stream(distorted_video, layout, height, width)
+    if layout_d != layout:
+        raise ValueError("reference and distorted streams must share a pixel layout")
     sse, ssim, sizes = frame_quality(ref, dist, layout, ssim_mode, height, width)
     comps = LAYOUTS[layout][1]
     # FFmpeg lists rgb components in r,g,b order whatever the packing
@@ -104,6 +119,62 @@ def run_ffmpeg_metrics(reference_video, distorted_video, psnr_log, ssim_log, vma
         for i in range(ssim.shape[0]):
             f.write(ssim_stats_line(i + 1, [ssim[i][j] for j in order], [sizes[j] for j in order], names))
     return None
+
+
+def thread_safe_update_csv(metrics, csv_file="video_quality_data.csv"):
+    """video_processing.py:44-68 — append one row, header only when the file is new (no pandas needed)."""
+    import csv
+    import threading
+    global _csv_lock
+    try:
+        _csv_lock
+    except NameError:
+        _csv_lock = threading.Lock()
+    exists = os.path.isfile(csv_file)
+    with _csv_lock:
+        with open(csv_file, "a", newline="") as f:
+            wr = csv.writer(f)
+            if not exists:
+                wr.writerow(list(metrics.keys()))
+            wr.writerow(list(metrics.values()))
+
+
+def process_video_and_extract_metrics(input_video, encoded_video, config, csv_file="video_quality_data.csv",
+                                      bitrate=0, frame_rate=30.0, column_order="reference"):
+    """video_processing.py:180-267 minus the libx264 encode and ffprobe steps (external codec, out of
+    scope): both streams arrive decoded.  Quality metrics compare input vs encoded (:216); complexity is
+    computed on the ENCODED stream (:242-243).  column_order="reference" keeps the reference's unpacking of
+    the 8-tuple (:235-242), which shifts five labels; "fixed" uses the tuple's true order."""
+    import tempfile
+    import uuid
+    from . import complexity_metrics as cm
+    crf = config.get("crf", 23)
+    rw, rh = config.get("resize_width", 64), config.get("resize_height", 64)
+    interval = config.get("frame_interval", 10)
+    uid = uuid.uuid4().hex
+    tmp = tempfile.gettempdir()
+    psnr_log, ssim_log, vmaf_log = (os.path.join(tmp, "%s_%s.log" % (k, uid)) for k in ("psnr", "ssim", "vmaf"))
+    try:
+        run_ffmpeg_metrics(input_video, encoded_video, psnr_log, ssim_log, vmaf_log, config.get("vmaf_model_path"))
+        enc = _open_frames(encoded_video)
+        resolution = "%dx%d" % (enc.shape[2], enc.shape[1]) if hasattr(enc, "shape") else "%dx%d" % (enc.w, enc.h)
+        metrics = extract_metrics_from_logs(psnr_log, ssim_log, vmaf_log, input_video, crf, bitrate, resolution, frame_rate)
+        t = cm.calculate_average_scene_complexity(encoded_video, rw, rh, frame_interval=interval, fps=frame_rate)
+        if column_order == "reference":   # (:235-242) motion, dct, temporal, hist, edge, orb, colour, fps
+            names = ("Advanced Motion Complexity", "DCT Complexity", "Temporal DCT Complexity", "Histogram Complexity",
+                     "Edge Detection Complexity", "ORB Feature Complexity", "Color Histogram Complexity",
+                     "Framerate Variation")
+        else:                             # (:301-310) the order the tuple really has
+            names = ("Advanced Motion Complexity", "DCT Complexity", "Histogram Complexity", "Edge Detection Complexity",
+                     "ORB Feature Complexity", "Color Histogram Complexity", "Temporal DCT Complexity",
+                     "Framerate Variation")
+        metrics.update(dict(zip(names, t)))
+        thread_safe_update_csv(metrics, csv_file)
+        return metrics
+    finally:
+        for p in (psnr_log, ssim_log, vmaf_log):
+            if os.path.exists(p):
+                os.remove(p)
 
 
 def extract_metrics_from_logs(psnr_log, ssim_log, vmaf_log, video_file, crf, bitrate, resolution, frame_rate):

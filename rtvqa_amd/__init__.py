@@ -12,6 +12,6 @@ __path__.insert(0, _REAL)
 
 from . import _native  # noqa: E402,F401  (binding only; the .so loads on first Engine())
 from .engine import DeviceFrames, Engine  # noqa: E402,F401
-from . import complexity_metrics, pooling, synth, video_processing  # noqa: E402,F401
+from . import complexity_metrics, frames, pooling, synth, video_processing  # noqa: E402,F401
 
-__all__ = ["Engine", "DeviceFrames", "complexity_metrics", "video_processing", "pooling", "synth"]
+__all__ = ["Engine", "DeviceFrames", "complexity_metrics", "video_processing", "pooling", "synth", "frames"]

@@ -90,3 +90,35 @@ def test_run_ffmpeg_metrics_files(tmp_path):
     lines = open(pl_).read().splitlines()
     assert len(lines) == 3 and lines[2].startswith("n:3 mse_avg:0.00") and "psnr_avg:inf" in lines[2]
     assert re.match(r"n:1 mse_avg:\d+\.\d\d mse_r:\d+\.\d\d mse_g:\d+\.\d\d mse_b:\d+\.\d\d psnr_avg:\d+\.\d\d ", lines[0])
+
+
+def test_y4m_quality_and_pipeline_row(tmp_path):
+    """yuv420p streams from .y4m files (the planes FFmpeg would compare) and the CSV row of
+    process_video_and_extract_metrics, with the reference's label shift reproduced or fixed."""
+    import csv
+    from rtvqa_amd import frames, synth
+    from rtvqa_amd import video_processing as vp
+    from rtvqa_amd.engine import yuv420p_planes
+    h, w = 72, 104
+    ref = _clip(25, h, w, seed=6)
+    enc = synth.distort(ref)
+    yr, yd = frames.bgr_to_yuv420p(ref[:3]), frames.bgr_to_yuv420p(enc[:3])
+    pr, pd_ = str(tmp_path / "r.y4m"), str(tmp_path / "d.y4m")
+    frames.write_y4m(pr, yr, h, w)
+    frames.write_y4m(pd_, yd, h, w)
+    pl_, sl_ = str(tmp_path / "p.log"), str(tmp_path / "s.log")
+    vp.run_ffmpeg_metrics(pr, pd_, pl_, sl_, str(tmp_path / "v.json"), ssim_mode="ffmpeg")
+    line = open(sl_).read().splitlines()[0]
+    sse, ssim = pl.frame_quality(yr[0], yd[0], yuv420p_planes(h, w), "ffmpeg")
+    assert line.startswith("n:1 Y:%f U:%f V:%f All:" % tuple(ssim))
+    assert open(pl_).read().startswith("n:1 mse_avg:%0.2f mse_y:%0.2f" % (sum(sse) / (1.5 * h * w), sse[0] / (h * w)))
+    cfg = {"crf": 23, "resize_width": 64, "resize_height": 64, "frame_interval": 10}
+    m_ref = vp.process_video_and_extract_metrics(ref, enc, cfg, csv_file=str(tmp_path / "a.csv"))
+    m_fix = vp.process_video_and_extract_metrics(ref, enc, cfg, csv_file=str(tmp_path / "a.csv"), column_order="fixed")
+    want = pl.calculate_average_scene_complexity(list(enc), 64, 64, frame_interval=10, dct_mode="full")
+    assert m_fix["Histogram Complexity"] == pytest.approx(float(want[2]), rel=1e-6)
+    assert m_ref["Temporal DCT Complexity"] == m_fix["Histogram Complexity"]       # the reference's shifted label
+    assert m_fix["Temporal DCT Complexity"] == pytest.approx(float(want[6]), rel=RTOL)
+    assert m_ref["Resolution (px)"] == "104x72" and "PSNR" in m_ref and "SSIM" in m_ref
+    rows = list(csv.reader(open(str(tmp_path / "a.csv"))))
+    assert len(rows) == 3 and rows[0][0] == "Bitrate (kbps)"
