@@ -103,6 +103,62 @@ __global__ __launch_bounds__(256, MINW) void k_dct8(const uint8_t *__restrict__ 
     }
 }
 
+// Paired variant: the energy transform (of curr) and the temporal transform (of prev - curr) run as the
+// two halves of ONE float2 transform, so every butterfly is a packed instruction.  128 VGPRs of
+// accumulator + inputs => 2 waves/SIMD; the next block's bytes are fetched before this block's arithmetic.
+__global__ __launch_bounds__(256, 2) void k_dct8_pair(const uint8_t *__restrict__ planes, int pitch,
+                                                      int64_t plane_stride, int h, int w, int first_has_prev,
+                                                      double *__restrict__ partials)
+{
+    __shared__ double red[4];
+    const int f = blockIdx.y;
+    const uint8_t *curr = planes + (int64_t)(f + 1) * plane_stride;
+    const uint8_t *prev = planes + (int64_t)f * plane_stride;
+    const bool temporal = (f > 0 || first_has_prev);
+    const int nbx = (w + 7) >> 3, nby = (h + 7) >> 3;
+    const int nblk = nbx * nby;
+    double acc_e = 0, acc_t = 0;
+    int b = blockIdx.x * 256 + threadIdx.x;
+    uint32_t clo[8], chi[8], plo[8], phi[8];
+    if (b < nblk) {
+        load_block_u8(curr, pitch, h, w, b / nbx, b % nbx, clo, chi);
+        load_block_u8(temporal ? prev : curr, pitch, h, w, b / nbx, b % nbx, plo, phi);
+    }
+    while (b < nblk) {
+        vqa_f2 v[64];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c0 = (clo[r] >> (8 * k)) & 0xff, p0 = (plo[r] >> (8 * k)) & 0xff;
+                const int c1 = (chi[r] >> (8 * k)) & 0xff, p1 = (phi[r] >> (8 * k)) & 0xff;
+                v[8 * r + k] = vqa_f2{(float)c0, (float)(p0 - c0)};
+                v[8 * r + 4 + k] = vqa_f2{(float)c1, (float)(p1 - c1)};
+            }
+        }
+        // prefetch the next block of this lane while the transform runs
+        const int bn = b + gridDim.x * 256;
+        if (bn < nblk) {
+            load_block_u8(curr, pitch, h, w, bn / nbx, bn % nbx, clo, chi);
+            load_block_u8(temporal ? prev : curr, pitch, h, w, bn / nbx, bn % nbx, plo, phi);
+        }
+        dct8x8_x2(v);
+        float e = 0, t = 0;
+#pragma unroll
+        for (int i = 0; i < 64; i++) { e = fmaf(v[i].x, v[i].x, e); t += fabsf(v[i].y); }
+        acc_e += (double)e;
+        acc_t += (double)t;
+        b = bn;
+    }
+    const double be = block_sum(acc_e, red);
+    const double bt = block_sum(acc_t, red);
+    if (threadIdx.x == 0) {
+        double *o = partials + ((int64_t)f * gridDim.x + blockIdx.x) * 2;
+        o[0] = be;
+        o[1] = temporal ? bt : 0.0;
+    }
+}
+
 // Deterministic second stage: one thread per frame adds the per-block partials
 // in a fixed order and stores them into the result records.
 __global__ void k_dct_finalize(const double *__restrict__ partials, int pb, int n, vqa_frame_metrics *__restrict__ res,
@@ -129,7 +185,7 @@ static int dct_variant()
     if (v < 0) {
         const char *e = getenv("VQA_DCT_VARIANT");
         v = e ? atoi(e) : 0;
-        if (v < 0 || v > 2) v = 0;
+        if (v < 0 || v > 3) v = 0;
     }
     return v;
 }
@@ -156,6 +212,13 @@ void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane
     if (n <= 0 || (!energy && !temporal)) return;
     const int pb = dct8_blocks_per_frame(h, w);
     dim3 grid(pb, n);
+    if (dct_variant() == 3 && energy && temporal) { // A/B: float2-paired transform
+        hipLaunchKernelGGL(k_dct8_pair, grid, dim3(256), 0, st, planes, pitch, plane_stride, h, w, (int)first_has_prev,
+                           partials);
+        hipLaunchKernelGGL(k_dct_finalize, dim3((n + 63) / 64), dim3(64), 0, st, partials, pb, n, res, 1, 1,
+                           (int)first_has_prev);
+        return;
+    }
     switch (dct_variant()) { // A/B knob (VQA_DCT_VARIANT): min waves/SIMD 3 (default), 1, 4
     case 1: launch_dct8_v<1>(st, grid, planes, pitch, plane_stride, h, w, energy, temporal, first_has_prev, partials); break;
     case 2: launch_dct8_v<4>(st, grid, planes, pitch, plane_stride, h, w, energy, temporal, first_has_prev, partials); break;

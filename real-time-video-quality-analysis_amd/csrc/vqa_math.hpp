@@ -55,6 +55,41 @@ VQA_HD void dct8(float *v)
     v[7 * STRIDE] = c7 * d0 - c5 * d1 + c3 * d2 - c1 * d3;
 }
 
+#if defined(__HIPCC__)
+// The same butterflies on float2 values: two independent transforms ride in the two halves of every
+// register pair, so each add/mul/fma below is one packed instruction (v_pk_add/mul/fma_f32).
+typedef float vqa_f2 __attribute__((ext_vector_type(2)));
+template <int STRIDE>
+__device__ __forceinline__ void dct8_x2(vqa_f2 *v)
+{
+    auto K = [](float c) { return vqa_f2{c, c}; };
+    auto fma2 = [](vqa_f2 a, vqa_f2 b, vqa_f2 c) { return __builtin_elementwise_fma(a, b, c); };
+    const float r8 = 0.35355339059327373f, c1 = 0.49039264020161522f, c2 = 0.46193976625564337f,
+                c3 = 0.41573480615127262f, c5 = 0.27778511650980114f, c6 = 0.19134171618254492f,
+                c7 = 0.09754516100806417f;
+    const vqa_f2 x0 = v[0 * STRIDE], x1 = v[1 * STRIDE], x2 = v[2 * STRIDE], x3 = v[3 * STRIDE];
+    const vqa_f2 x4 = v[4 * STRIDE], x5 = v[5 * STRIDE], x6 = v[6 * STRIDE], x7 = v[7 * STRIDE];
+    const vqa_f2 s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
+    const vqa_f2 d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
+    const vqa_f2 t0 = s0 + s3, t1 = s1 + s2, t2 = s0 - s3, t3 = s1 - s2;
+    v[0 * STRIDE] = (t0 + t1) * K(r8);
+    v[4 * STRIDE] = (t0 - t1) * K(r8);
+    v[2 * STRIDE] = fma2(K(c2), t2, K(c6) * t3);
+    v[6 * STRIDE] = fma2(K(c6), t2, K(-c2) * t3);
+    v[1 * STRIDE] = fma2(K(c1), d0, fma2(K(c3), d1, fma2(K(c5), d2, K(c7) * d3)));
+    v[3 * STRIDE] = fma2(K(c3), d0, fma2(K(-c7), d1, fma2(K(-c1), d2, K(-c5) * d3)));
+    v[5 * STRIDE] = fma2(K(c5), d0, fma2(K(-c1), d1, fma2(K(c7), d2, K(c3) * d3)));
+    v[7 * STRIDE] = fma2(K(c7), d0, fma2(K(-c5), d1, fma2(K(c3), d2, K(-c1) * d3)));
+}
+__device__ __forceinline__ void dct8x8_x2(vqa_f2 *v)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) dct8_x2<1>(v + 8 * r);
+#pragma unroll
+    for (int c = 0; c < 8; c++) dct8_x2<8>(v + c);
+}
+#endif
+
 // 2-D 8x8 DCT of a row-major block held in 64 registers.
 VQA_HD void dct8x8(float *v)
 {
