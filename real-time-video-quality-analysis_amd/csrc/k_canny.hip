@@ -25,6 +25,8 @@
 #include "vqa_kernels.hpp"
 #include "vqa_math.hpp"
 
+#include <cstdlib>
+
 namespace vqa {
 
 constexpr int TW = 64, TH = 32;
@@ -135,6 +137,153 @@ __global__ __launch_bounds__(256) void k_canny_nms(const uint8_t *__restrict__ g
     if (tid == 0) {
         if (s_cnt[0]) atomicAdd(&res[f].edge_strong, s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&res[f].edge_weak, s_cnt[1]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stage 1, register-rolling form (k_canny_nms2): no LDS, no barriers, no cross-lane traffic until the
+// bit-plane words are assembled.  A wave covers 256 columns and marches down a 64-row strip; every lane
+// owns FOUR consecutive pixels.  Per row it loads the 8 gray bytes x-2 .. x+5 (clamped = replicated
+// border), forms the horizontal Sobel partial sums for pixels x-1 .. x+4 as packed 16-bit pairs
+// (v_pk_add/sub/mad_u16: two pixels per instruction), and keeps three rows of them in registers; the
+// vertical combination gives gx, gy and |gx|+|gy| for the SAME six pixels, so the magnitudes of the
+// lane's left and right neighbours (needed by NMS) are computed locally instead of fetched.  Three rows
+// of magnitudes roll in registers; NMS + double threshold runs on the lane's four pixels; the four
+// class bits per lane are OR-reduced over each 16-lane DPP row into one u64 bit-plane word per tile row.
+// ---------------------------------------------------------------------------
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+struct nms_rows {
+    s2 h1[3][3], h2[3][3]; // [row slot][pixel pair (-1,0) (1,2) (3,4)]
+    s2 mag[3][3];
+    s2 gx[3][3], gy[3][3];
+};
+
+__device__ __forceinline__ uint32_t dpp_or_row(uint32_t v)
+{
+    // inclusive prefix OR over the 16 lanes of a DPP row: lane 15 ends up with the OR of all 16
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); // row_shr:8
+    return v;
+}
+
+template <int PH>
+__device__ __forceinline__ void nms2_step(nms_rows &S, int j, const uint8_t *__restrict__ g, int pitch, int h, int w,
+                                          int y0, int xm2, const s2 (&cmask)[3], int low, int high, int f, int tx,
+                                          int ww, int tiles_y, unsigned long long *__restrict__ strong,
+                                          unsigned long long *__restrict__ weak, unsigned &n_strong, unsigned &n_weak)
+{
+    constexpr int A = (PH + 1) % 3, B = (PH + 2) % 3, Cc = PH; // rows R-2, R-1, R of the h window
+    const int lane = lane_id();
+    const int R = y0 - 2 + j;
+    // ---- horizontal partial sums of gray row R (vertical border: replicate)
+    {
+        const uint8_t *row = g + (int64_t)min(max(R, 0), h - 1) * pitch;
+        int p[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) p[k] = row[min(max(xm2 + k, 0), w - 1)];
+        const s2 P0 = {(short)p[0], (short)p[1]}, Q0 = {(short)p[1], (short)p[2]}, P1 = {(short)p[2], (short)p[3]};
+        const s2 Q1 = {(short)p[3], (short)p[4]}, P2 = {(short)p[4], (short)p[5]}, Q2 = {(short)p[5], (short)p[6]};
+        const s2 P3 = {(short)p[6], (short)p[7]};
+        S.h1[Cc][0] = P1 - P0; S.h1[Cc][1] = P2 - P1; S.h1[Cc][2] = P3 - P2;
+        S.h2[Cc][0] = P0 + Q0 + Q0 + P1; S.h2[Cc][1] = P1 + Q1 + Q1 + P2; S.h2[Cc][2] = P2 + Q2 + Q2 + P3;
+    }
+    // ---- gradient and magnitude of row R-1 (0 outside the image)
+    {
+        const bool row_in = (R - 1 >= 0) && (R - 1 < h);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const s2 gx = S.h1[A][i] + S.h1[B][i] + S.h1[B][i] + S.h1[Cc][i];
+            const s2 gy = S.h2[Cc][i] - S.h2[A][i];
+            const s2 m = (__builtin_elementwise_abs(gx) + __builtin_elementwise_abs(gy)) & cmask[i];
+            S.gx[B][i] = gx;
+            S.gy[B][i] = gy;
+            S.mag[B][i] = row_in ? m : s2{0, 0};
+        }
+    }
+    // ---- NMS + double threshold of row R-2: magnitudes of rows R-3 (slot Cc), R-2 (A), R-1 (B)
+    const int y = R - 2;
+    if (j >= 4 && y < h) { // wave-uniform
+        // six magnitudes per row: index 0..5 <-> pixels -1..4
+        int up[6], md[6], dn[6];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            up[2 * i] = S.mag[Cc][i].x; up[2 * i + 1] = S.mag[Cc][i].y;
+            md[2 * i] = S.mag[A][i].x;  md[2 * i + 1] = S.mag[A][i].y;
+            dn[2 * i] = S.mag[B][i].x;  dn[2 * i + 1] = S.mag[B][i].y;
+        }
+        const int gxs[4] = {S.gx[A][0].y, S.gx[A][1].x, S.gx[A][1].y, S.gx[A][2].x};
+        const int gys[4] = {S.gy[A][0].y, S.gy[A][1].x, S.gy[A][1].y, S.gy[A][2].x};
+        uint32_t nib_s = 0, nib_w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int nb[8] = {up[k], up[k + 1], up[k + 2], md[k], md[k + 2], dn[k], dn[k + 1], dn[k + 2]};
+            const int c = canny_classify(md[k + 1], gxs[k], gys[k], nb, low, high);
+            nib_s |= (uint32_t)(c == 2) << k;
+            nib_w |= (uint32_t)(c == 1) << k;
+        }
+        // lane (16 q + i) holds columns 4 i .. 4 i + 3 of tile-row word q: bits 4 i .. 4 i + 3
+        const int i16 = lane & 15;
+        const uint32_t sh = (uint32_t)(i16 & 7) * 4;
+        uint32_t s_lo = i16 < 8 ? nib_s << sh : 0u, s_hi = i16 < 8 ? 0u : nib_s << sh;
+        uint32_t w_lo = i16 < 8 ? nib_w << sh : 0u, w_hi = i16 < 8 ? 0u : nib_w << sh;
+        s_lo = dpp_or_row(s_lo); s_hi = dpp_or_row(s_hi);
+        w_lo = dpp_or_row(w_lo); w_hi = dpp_or_row(w_hi);
+        if (i16 == 15 && tx < ww) {
+            const int64_t o = bp_index(f, y, tx, ww, tiles_y);
+            strong[o] = (unsigned long long)s_lo | ((unsigned long long)s_hi << 32);
+            weak[o] = (unsigned long long)w_lo | ((unsigned long long)w_hi << 32);
+            n_strong += __popc(s_lo) + __popc(s_hi);
+            n_weak += __popc(w_lo) + __popc(w_hi);
+        }
+    }
+}
+
+// grid = (ceil(w / 256), ceil(h / 64), n_frames), block = 64 (one wave)
+__global__ __launch_bounds__(64) void k_canny_nms2(const uint8_t *__restrict__ gray, int pitch, int64_t plane_stride,
+                                                   int h, int w, int low, int high,
+                                                   unsigned long long *__restrict__ strong,
+                                                   unsigned long long *__restrict__ weak, int ww,
+                                                   vqa_frame_metrics *__restrict__ res)
+{
+    const int f = blockIdx.z;
+    const int lane = lane_id();
+    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * 64;
+    const int x = x0 + 4 * lane; // first of the lane's four pixels
+    const uint8_t *g = gray + (int64_t)f * plane_stride;
+    const int tiles_y = (h + 63) >> 6;
+    const int tx = blockIdx.x * 4 + (lane >> 4);
+    // pixels -1..4 of this lane that lie inside the image keep their magnitude, the others read 0
+    s2 cmask[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int xa = x - 1 + 2 * i, xb = xa + 1;
+        cmask[i] = s2{(short)((xa >= 0 && xa < w) ? -1 : 0), (short)((xb >= 0 && xb < w) ? -1 : 0)};
+    }
+    nms_rows S;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            S.h1[r][i] = S.h2[r][i] = S.mag[r][i] = S.gx[r][i] = S.gy[r][i] = s2{0, 0};
+        }
+    unsigned n_strong = 0, n_weak = 0;
+    const int rows_out = min(64, h - y0);
+    const int steps = rows_out + 4;
+    for (int j0 = 0; j0 < steps; j0 += 3) {
+        nms2_step<0>(S, j0, g, pitch, h, w, y0, x - 2, cmask, low, high, f, tx, ww, tiles_y, strong, weak, n_strong, n_weak);
+        if (j0 + 1 < steps)
+            nms2_step<1>(S, j0 + 1, g, pitch, h, w, y0, x - 2, cmask, low, high, f, tx, ww, tiles_y, strong, weak, n_strong, n_weak);
+        if (j0 + 2 < steps)
+            nms2_step<2>(S, j0 + 2, g, pitch, h, w, y0, x - 2, cmask, low, high, f, tx, ww, tiles_y, strong, weak, n_strong, n_weak);
+    }
+    n_strong = wave_sum(n_strong);
+    n_weak = wave_sum(n_weak);
+    if (lane == 0) {
+        if (n_strong) atomicAdd(&res[f].edge_strong, n_strong);
+        if (n_weak) atomicAdd(&res[f].edge_weak, n_weak);
     }
 }
 
@@ -327,9 +476,16 @@ void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t pl
                       vqa_frame_metrics *res)
 {
     if (n <= 0) return;
-    const canny_geom g = canny_tiles(h, w);
-    hipLaunchKernelGGL(k_canny_nms, dim3(g.tiles_x, g.tiles_y, n), dim3(256), 0, st, gray, pitch, plane_stride, h, w,
-                       low, high, strong, weak, (w + 63) / 64, res);
+    static int variant = -1; // A/B knob (VQA_NMS_VARIANT): 0 = register-rolling kernel (default), 1 = LDS-tile kernel
+    if (variant < 0) { const char *e = getenv("VQA_NMS_VARIANT"); variant = e ? atoi(e) : 0; }
+    if (variant == 1) {
+        const canny_geom g = canny_tiles(h, w);
+        hipLaunchKernelGGL(k_canny_nms, dim3(g.tiles_x, g.tiles_y, n), dim3(256), 0, st, gray, pitch, plane_stride, h, w,
+                           low, high, strong, weak, (w + 63) / 64, res);
+    } else {
+        hipLaunchKernelGGL(k_canny_nms2, dim3((w + 255) / 256, (h + 63) / 64, n), dim3(64), 0, st, gray, pitch,
+                           plane_stride, h, w, low, high, strong, weak, (w + 63) / 64, res);
+    }
 }
 
 static hyst_args make_hyst_args(unsigned long long *strong, const unsigned long long *weak, int h, int w,

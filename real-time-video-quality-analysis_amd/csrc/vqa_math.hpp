@@ -109,6 +109,9 @@ VQA_HD void dct8x8(float *v)
 // returns 0 = not an edge, 1 = weak candidate, 2 = strong edge
 VQA_HD int canny_classify(int m, int gx, int gy, const int nb[8], int low, int high)
 {
+    // Deliberately BRANCHY: on real frames most pixels fail m > low, and a wave whose lanes all fail
+    // skips the sector test outright.  A select-only (branchless) form of the same truth table measured
+    // 1.5x (register kernel) to 2x (LDS kernel) slower on natural content.
     if (!(m > low)) return 0;
     const int ax = gx < 0 ? -gx : gx;
     const int ay = (gy < 0 ? -gy : gy) << 15;
