@@ -217,6 +217,16 @@ __device__ __forceinline__ void nms2_step(nms_rows &S, int j, const uint8_t *__r
         const int gxs[4] = {S.gx[A][0].y, S.gx[A][1].x, S.gx[A][1].y, S.gx[A][2].x};
         const int gys[4] = {S.gy[A][0].y, S.gy[A][1].x, S.gy[A][1].y, S.gy[A][2].x};
         uint32_t nib_s = 0, nib_w = 0;
+        // a row of 256 pixels with no gradient above `low` (flat regions) skips NMS and the word assembly
+        const bool any_cand = __any(max(max(md[1], md[2]), max(md[3], md[4])) > low);
+        if (!any_cand) {
+            if ((lane & 15) == 15 && tx < ww) {
+                const int64_t o = bp_index(f, y, tx, ww, tiles_y);
+                strong[o] = 0ull;
+                weak[o] = 0ull;
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int nb[8] = {up[k], up[k + 1], up[k + 2], md[k], md[k + 2], dn[k], dn[k + 1], dn[k + 2]};
@@ -464,6 +474,52 @@ __global__ __launch_bounds__(256) void k_canny_hyst_list(hyst_args A, const unsi
     }
 }
 
+// Tail of the fixpoint without the host: ONE workgroup per frame keeps relaxing that frame's own work
+// list, round after round, until a round enqueues nothing.  Rounds are separated by an agent-scope
+// fence + workgroup barrier: the promotions a round stored are released to L2 and this CU's L1 is
+// invalidated before the next round loads them (every producer and consumer of a frame's tiles is in
+// this one workgroup, so nothing outside it needs to see the flag traffic).  The loop is bounded.
+__global__ __launch_bounds__(1024) void k_canny_hyst_tail(hyst_args A, unsigned *__restrict__ list0,
+                                                         unsigned *__restrict__ cnt0, unsigned *__restrict__ q0,
+                                                         unsigned *__restrict__ list1, unsigned *__restrict__ cnt1,
+                                                         unsigned *__restrict__ q1, int first_in)
+{
+    __shared__ unsigned s_n;
+    const unsigned f = blockIdx.x, tpf = (unsigned)(A.tiles_y * A.ww);
+    unsigned *lists[2] = {list0, list1}, *cnts[2] = {cnt0, cnt1}, *qs[2] = {q0, q1};
+    int in = first_in;
+    for (int round = 0; round < (1 << 16); round++) {
+        if (threadIdx.x == 0) {
+            s_n = cnts[in][f];
+            cnts[in ^ 1][f] = 0; // the list this round builds ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // ... acknowledged by L2 before any wave's atomicAdd on it
+        }
+        __syncthreads();
+        const unsigned n = s_n;
+        if (n == 0) break;
+        A.queued = qs[in ^ 1];
+        A.out_list = lists[in ^ 1];
+        A.out_count = cnts[in ^ 1];
+        for (unsigned i = wave_id(); i < n; i += blockDim.x / 64) {
+            const unsigned tile = lists[in][f * tpf + i];
+            if (lane_id() == 0) qs[in][tile] = 0;
+            relax_tile(A, tile);
+        }
+        // hand-off to the next round (guide G16): every storing wave drains its stores, the workgroup
+        // meets, ONE lane releases to L2 and then invalidates this CU's L1, the workgroup meets again.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        in ^= 1;
+    }
+}
+
 // edge_count so far holds the promotions; add the strong pixels.
 __global__ void k_canny_finish(int n, vqa_frame_metrics *__restrict__ res)
 {
@@ -516,6 +572,18 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
     hipLaunchKernelGGL(k_canny_hyst_list, dim3(8, n), dim3(256), 0, st,
                        make_hyst_args(strong, weak, h, w, out_queued, out_list, out_count, res), in_list, in_count,
                        in_queued);
+}
+
+// rounds 2.. to convergence, one workgroup per frame, no host involvement.  lists/counts/queued: the two
+// per-frame work lists; first_in = index of the list the first tail round consumes.
+void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
+                            int w, unsigned *list0, unsigned *cnt0, unsigned *q0, unsigned *list1, unsigned *cnt1,
+                            unsigned *q1, int first_in, vqa_frame_metrics *res)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_canny_hyst_tail, dim3(n), dim3(1024), 0, st,
+                       make_hyst_args(strong, weak, h, w, nullptr, nullptr, nullptr, res), list0, cnt0, q0, list1, cnt1,
+                       q1, first_in);
 }
 
 void launch_canny_finish(hipStream_t st, int n, vqa_frame_metrics *res)

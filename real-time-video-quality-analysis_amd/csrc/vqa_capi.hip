@@ -501,26 +501,19 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             prof_scope ps_(c, VQA_K_CANNY_HYST);
             launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], counts + n, res);
         }
-        round = 1;
-        const int GROUP = 8, MAX_ROUNDS = 1 << 20;
-        for (;;) {
-            {
-                prof_scope ps_(c, VQA_K_CANNY_HYST);
-                for (int k = 0; k < GROUP; k++, round++) {
-                    const int in = round & 1, out = in ^ 1;
-                    HIPCHK(c, hipMemsetAsync(counts + out * n, 0, sizeof(uint32_t) * n, st));
-                    launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in * n,
-                                           queued[out], lists[out], counts + out * n, res);
-                }
+        {
+            // rounds 1..WIDE (still many tiles): wide grid over the per-frame lists; then the tail kernel
+            // finishes every frame on its own workgroup with no host round-trip.
+            prof_scope ps_(c, VQA_K_CANNY_HYST);
+            const int WIDE = 4;
+            for (round = 1; round <= WIDE; round++) {
+                const int in = round & 1, out = in ^ 1;
+                HIPCHK(c, hipMemsetAsync(counts + out * n, 0, sizeof(uint32_t) * n, st));
+                launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in * n,
+                                       queued[out], lists[out], counts + out * n, res);
             }
-            // the list the next round would read
-            HIPCHK(c, hipMemcpyAsync(c->again_host_v, counts + (round & 1) * n, sizeof(uint32_t) * n,
-                                     hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            uint32_t pending = 0;
-            for (int i = 0; i < n; i++) pending |= ((const uint32_t *)c->again_host_v)[i];
-            if (!pending) break;
-            if (round >= MAX_ROUNDS) { c->last_err = "canny hysteresis did not converge"; return VQA_ERR_HIP; }
+            launch_canny_hyst_tail(st, strong, weak, n, ph, pw, lists[0], counts, queued[0], lists[1], counts + n,
+                                   queued[1], round & 1, res);
         }
         c->canny_rounds = (uint32_t)round;
         launch_canny_finish(st, n, res);
