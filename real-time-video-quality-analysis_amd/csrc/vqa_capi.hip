@@ -45,8 +45,6 @@ struct vqa_ctx {
     // pinned host staging
     void *res_host = nullptr; size_t res_host_cap = 0;
     void *qres_host = nullptr; size_t qres_host_cap = 0;
-    uint32_t *again_host = nullptr;
-    void *again_host_v = nullptr; size_t again_host_cap = 0;
 
     std::map<std::tuple<int, int, int, int>, resize_tabs> tabs;
     std::map<int, float *> dct_mats;
@@ -57,7 +55,6 @@ struct vqa_ctx {
     // geometry of the last complexity batch (debug reads)
     int last_n = 0, last_h = 0, last_w = 0, last_ph = 0, last_pw = 0, last_pp = 0, last_gp = 0;
     bool last_resized = false, last_has_full = false, last_has_state = false, last_has_planes = false;
-    uint32_t canny_rounds = 0;
 
     // per-kernel timing
     bool prof_on = false;
@@ -255,8 +252,7 @@ int vqa_create(int device, vqa_ctx **out)
     vqa_ctx *c = new (std::nothrow) vqa_ctx();
     if (!c) return VQA_ERR_OOM;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void **)&c->again_host, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return VQA_ERR_HIP;
     }
@@ -282,8 +278,6 @@ int vqa_destroy(vqa_ctx *c)
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->qres_host) (void)hipHostFree(c->qres_host);
-    if (c->again_host) (void)hipHostFree(c->again_host);
-    if (c->again_host_v) (void)hipHostFree(c->again_host_v);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return VQA_OK;
@@ -465,7 +459,6 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
 
     // ---- Canny (input: plane B)
     c->last_has_state = false;
-    c->canny_rounds = 0;
     if (want_e) {
         const int ww = (pw + 63) / 64;
         const size_t words = (size_t)n * ((ph + 63) / 64) * ww * 64; // tile-major bit-planes
@@ -480,8 +473,6 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         if (rc) return rc;
         rc = ensure(c, c->again_dev, sizeof(uint32_t) * 2 * n);   // per-frame append counters of the two lists
         if (rc) return rc;
-        rc = ensure_pinned(c, c->again_host_v, c->again_host_cap, sizeof(uint32_t) * n);
-        if (rc) return rc;
         unsigned long long *strong = (unsigned long long *)c->state.p, *weak = strong + words;
         unsigned *queued[2] = {(unsigned *)c->tile_flags.p, (unsigned *)c->tile_flags.p + ntiles};
         unsigned *lists[2] = {(unsigned *)c->dirty0.p, (unsigned *)c->dirty1.p};
@@ -494,8 +485,8 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             prof_scope ps_(c, VQA_K_CANNY_NMS);
             launch_canny_nms(st, pB, pp, plane_stride, n, ph, pw, lo, hi, strong, weak, res);
         }
-        // hysteresis to the fixpoint.  Round 0 relaxes every tile; round r > 0 relaxes the tiles that
-        // round r-1 enqueued into lists[r & 1].  One 4-byte readback per GROUP rounds.
+        // hysteresis to the fixpoint, entirely enqueued (no host readback).  Round 0 relaxes every tile;
+        // round r > 0 relaxes the tiles that round r-1 enqueued into lists[r & 1].
         int round = 0;
         {
             prof_scope ps_(c, VQA_K_CANNY_HYST);
@@ -515,7 +506,6 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             launch_canny_hyst_tail(st, strong, weak, n, ph, pw, lists[0], counts, queued[0], lists[1], counts + n,
                                    queued[1], round & 1, res);
         }
-        c->canny_rounds = (uint32_t)round;
         launch_canny_finish(st, n, res);
         c->last_has_state = true;
     }
