@@ -181,6 +181,24 @@ def test_canny_1080p_many_rounds(engine):
             assert int(rec[i]["edge_count"]) == cnt, (low, high, i)
 
 
+def test_canny_many_contents_one_batch(engine):
+    """24 different 720p frames (natural + noise + mixed) in ONE batch at two threshold pairs: every frame's
+    hysteresis runs through the wide rounds and the per-frame persistent tail concurrently with the others."""
+    from rtvqa_amd import _native as N
+    h, w = 720, 1280
+    fr = np.concatenate([_frames("natural", 3, h, w, seed=100 + s) for s in range(6)] +
+                        [_frames("noise", 2, h, w, seed=200)] +
+                        [(_frames("natural", 2, h, w, seed=300) // 2 + _frames("noise", 2, h, w, seed=301) // 8)] +
+                        [np.repeat(np.tile(np.arange(w, dtype=np.uint8)[None, :, None] // 3 * 3, (h, 1, 1)), 3, 2)[None]] +
+                        [_frames("natural", 1, h, w, seed=400)])
+    for low, high in ((100, 200), (25, 70)):
+        rec = engine.complexity(fr, mask=N.M_EDGE, canny=(low, high))
+        for i in range(fr.shape[0]):
+            cnt, strong, weak = co.canny(co.bgr2gray(fr[i]), low, high)
+            assert (int(rec[i]["edge_strong"]), int(rec[i]["edge_weak"]), int(rec[i]["edge_count"])) == \
+                (strong, weak, cnt), (low, high, i)
+
+
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("h,w", [(96, 128), (100, 200), (64, 80), (48, 48), (10, 300), (160, 272)])
 @pytest.mark.parametrize("kind", ["natural", "noise"])
