@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--ssim-mode", default="gauss", choices=["gauss", "ffmpeg"])
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="1 (default): one stream, clean per-kernel event times; 2: quality kernels on a second stream (+4-8%% fps, event times of overlapped kernels are inflated)")
+    ap.add_argument("--pixfmt", default="bgr24", choices=["bgr24", "yuv420p"],
+                    help="planes PSNR/SSIM compare: bgr24 (default: B,G,R of the packed frames) or yuv420p (Y + "
+                         "quarter-size U,V derived from the same frames: what FFmpeg compares for an H.264 clip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the rank logic)")
     args = ap.parse_args()
@@ -140,7 +143,8 @@ def main():
     import rtvqa_amd
     from rtvqa_amd import _native as N
     from rtvqa_amd import synth
-    from rtvqa_amd.engine import DeviceBuffer, DeviceFrames, bgr_planes
+    from rtvqa_amd.engine import DeviceBuffer, DeviceFrames, bgr_planes, yuv420p_planes
+    from rtvqa_amd.frames import bgr_to_yuv420p, frame_bytes_yuv420p
 
     # two contexts = two HIP streams on the same device: the VALU-bound SSIM launch overlaps the
     # memory/latency-bound complexity kernels and the host round-trips of the Canny fixpoint
@@ -150,6 +154,10 @@ def main():
     # ---- synthetic streams, generated in chunks and made resident in HBM before timing
     fbytes = h * w * 3
     ref_buf, dist_buf = DeviceBuffer(eng, fbytes * (B + 1)), DeviceBuffer(eng, fbytes * (B + 1))
+    yuv = args.pixfmt == "yuv420p"
+    ybytes = frame_bytes_yuv420p(h, w)
+    if yuv:
+        yref_buf, ydist_buf = DeviceBuffer(eng, ybytes * (B + 1)), DeviceBuffer(eng, ybytes * (B + 1))
     chunk = 32
     for a in range(0, B + 1, chunk):
         n = min(chunk, B + 1 - a)
@@ -157,6 +165,10 @@ def main():
         d = synth.distort(r, t0=a)
         N.check(eng.lib.vqa_copy_h2d(eng.ctx, ref_buf.ptr + a * fbytes, r.ctypes.data, r.nbytes), "h2d", eng.ctx)
         N.check(eng.lib.vqa_copy_h2d(eng.ctx, dist_buf.ptr + a * fbytes, d.ctypes.data, d.nbytes), "h2d", eng.ctx)
+        if yuv:
+            yr, yd = bgr_to_yuv420p(r), bgr_to_yuv420p(d)
+            N.check(eng.lib.vqa_copy_h2d(eng.ctx, yref_buf.ptr + a * ybytes, yr.ctypes.data, yr.nbytes), "h2d", eng.ctx)
+            N.check(eng.lib.vqa_copy_h2d(eng.ctx, ydist_buf.ptr + a * ybytes, yd.ctypes.data, yd.nbytes), "h2d", eng.ctx)
         eng.sync()
     ref_all = DeviceFrames(ref_buf.ptr, B + 1, h, w, owner=ref_buf)
     dist_all = DeviceFrames(dist_buf.ptr, B + 1, h, w, owner=dist_buf)
@@ -165,10 +177,16 @@ def main():
     mask = N.M_ALL if full else (N.M_DCT | N.M_TEMPORAL_DCT)
     params = eng.make_params(dct_mode=N.DCT_BLOCK8)
     planes = bgr_planes(h, w)
+    if yuv:  # quality kernels read the planar streams; the complexity kernels still read the BGR frames
+        planes = yuv420p_planes(h, w)
+        ref_b = DeviceFrames(yref_buf.ptr + ybytes, B, h, w, frame_stride=ybytes, row_stride=w, owner=yref_buf, channels=1)
+        dist_q = DeviceFrames(ydist_buf.ptr + ybytes, B, h, w, frame_stride=ybytes, row_stride=w, owner=ydist_buf, channels=1)
+    else:
+        dist_q = dist_b
     smode = N.SSIM_GAUSS if args.ssim_mode == "gauss" else N.SSIM_FFMPEG
 
     def step():
-        eng_q.quality_submit(ref_b, dist_b, planes, smode)
+        eng_q.quality_submit(ref_b, dist_q, planes, smode)
         eng.complexity_submit(dist_b, prev0, mask, params)
         q = eng_q.quality_wait()
         c = eng.complexity_wait()
@@ -215,9 +233,13 @@ def main():
     if rank == 0:
         P = h * w
         alg_bytes = {  # algorithmic HBM bytes per profiled launch group (SURVEY.md §8d x frames per launch)
-            "k_ssim_gauss": 2 * P * B * len(planes),  # one launch covers the B, G, R planes (2P each)
-            "k_ssim_ffmpeg": 2 * P * B * len(planes), "k_dct8": 2 * P * B,
-            "k_bgr2gray_hist": 4 * P * (B + 1), "k_canny_nms": 2 * P * B, "k_block_sad": 2 * P * B,
+            # bgr24: ONE launch covers the B, G, R planes (2P each).  yuv420p: two launches per step (Y: 2P,
+            # U+V: 2 * 2 * P/4), so the mean launch moves 1.5P per frame
+            "k_ssim_gauss": 2 * P * B * 3 if not yuv else int(1.5 * P * B),
+            "k_ssim_ffmpeg": 2 * P * B * 3 if not yuv else P * B,  # yuv420p: three planar launches, 3P in all
+            "k_dct8": 2 * P * B, "k_bgr2gray_hist": 4 * P * (B + 1),
+            "k_canny_nms": P * B + P * B // 4,  # reads gray, writes two bit-planes (P/8 each)
+            "k_block_sad": 2 * P * B,
         }
         kernels = {}
         for name, (ms, cnt) in prof.items():
@@ -253,7 +275,7 @@ def main():
                     % synth.GENERATOR_VERSION,
             "config": {"workload": wl["name"] if args.ssim_mode == "gauss" else
                        wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"), "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams,
-                       "resident": "HBM", "ssim_mode": args.ssim_mode, "parallelism": "1 stream/GPU x%d" % world},
+                       "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "parallelism": "1 stream/GPU x%d" % world},
             "roofline": roof, "kernels": kernels,
         }
         if cpu_line is not None:

@@ -33,9 +33,20 @@
 
 namespace vqa {
 
-// output rows per strip: strips of at most ~1100 rows, balanced (1080p: one strip, 2160p: two)
-static inline int ssim_strips(int h) { return (h - 10 + 1099) / 1100; }
-static inline int ssim_strip_rows(int h) { const int ns = ssim_strips(h); return (h - 10 + ns - 1) / ns; }
+// Row strips per plane.  Long strips amortise the 10-row vertical warm-up; but the chip holds ~1536
+// of these 256-thread workgroups at once (6 waves/SIMD), so a launch wants >= ~4 residency rounds of
+// workgroups or its tail runs on a part-empty chip.  strips = what the height needs (<= ~1100 rows each)
+// or what the workgroup count needs, whichever is larger, with strips never shorter than 64 rows.
+static inline int ssim_max_strips(int h) { const int s = (h - 10) / 64; return s < 1 ? 1 : s; }
+static inline int ssim_strips(int h, long long groups /* workgroups per strip row: n * planes * column blocks */)
+{
+    int ns = (h - 10 + 1099) / 1100;
+    const long long want = (6144 + groups - 1) / (groups > 0 ? groups : 1);
+    if (want > ns) ns = (int)(want > 4096 ? 4096 : want);
+    const int cap = ssim_max_strips(h);
+    return ns > cap ? cap : ns;
+}
+static inline int ssim_strip_rows(int h, int ns) { return (h - 10 + ns - 1) / ns; }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -230,8 +241,8 @@ int ssim_gauss_blocks(int h, int w)
 {
     if (h < 11 || w < 11) return 0;
     const int qout = ssim_qout();
-    const int ncb = (w - 10 + qout - 1) / qout, ns = ssim_strips(h);
-    return ncb * ns;
+    const int ncb = (w - 10 + qout - 1) / qout;
+    return ncb * ssim_max_strips(h); // upper bound: sizes the per-plane partials segment
 }
 
 // planes[idx[0..count)] share width, height, row_stride and pixel_step
@@ -243,7 +254,9 @@ void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dis
     const vqa_plane_desc &pd = planes[idx[0]];
     const int w = pd.width, h = pd.height;
     const int qout = ssim_qout();
-    const int ncb = (w - 10 + qout - 1) / qout, ns = ssim_strips(h), QS = ssim_strip_rows(h);
+    const int ncb = (w - 10 + qout - 1) / qout;
+    const int ns0 = ssim_strips(h, (long long)n * count * ncb), QS = ssim_strip_rows(h, ns0);
+    const int ns = (h - 10 + QS - 1) / QS; // strips actually needed at this strip height
     const int bpp = ncb * ns;
     plane_group g;
     g.count = count;
