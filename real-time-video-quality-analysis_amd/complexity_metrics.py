@@ -318,13 +318,13 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
     for a in range(0, len(sel), batch_size):
         chunk = sel[a:a + batch_size]
         if isinstance(fr, DeviceFrames):
-            if frame_interval == 1:
-                batch = fr.slice(int(chunk[0]), int(chunk[-1]) + 1)
-            else:
-                raise NotImplementedError("device-resident sources need frame_interval == 1")
+            # every frame_interval-th frame, zero-copy: the batch is a strided view of the resident clip
+            batch = DeviceFrames(fr.ptr + int(chunk[0]) * fr.frame_stride, len(chunk), fr.h, fr.w,
+                                 frame_stride=fr.frame_stride * frame_interval, row_stride=fr.row_stride,
+                                 owner=fr, channels=fr.channels)
             prev0 = fr.frame(int(prev_i))
         else:
-            batch = np.ascontiguousarray(fr[chunk]) if frame_interval != 1 else np.asarray(fr[chunk[0]:chunk[-1] + 1])
+            batch = fr[int(chunk[0]):int(chunk[-1]) + 1:frame_interval]  # strided view: only selected frames are uploaded
             prev0 = np.asarray(fr[prev_i])
         rec = eng.complexity(batch, prev0=prev0, mask=mask, params=params)
         for j, r in enumerate(rec):

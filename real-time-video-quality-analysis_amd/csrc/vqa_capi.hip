@@ -364,10 +364,18 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     // ---- bring frames to the device if they are on the host
     const uint8_t *dframes = frames, *dprev = prev0;
     if (mem_kind == VQA_MEM_HOST) {
-        const size_t span = (size_t)(n - 1) * frame_stride + (size_t)h * row_stride;
-        int rc = ensure(c, c->stage_frames, span);
+        const size_t fbytes = (size_t)h * row_stride;
+        int rc = ensure(c, c->stage_frames, fbytes * n);
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->stage_frames.p, frames, span, hipMemcpyHostToDevice, st));
+        if ((size_t)frame_stride == fbytes) {
+            HIPCHK(c, hipMemcpyAsync(c->stage_frames.p, frames, fbytes * n, hipMemcpyHostToDevice, st));
+        } else {
+            // strided selection (every k-th frame of a clip): only the selected frames cross PCIe
+            for (int i = 0; i < n; i++)
+                HIPCHK(c, hipMemcpyAsync((uint8_t *)c->stage_frames.p + fbytes * i, frames + (int64_t)i * frame_stride,
+                                         fbytes, hipMemcpyHostToDevice, st));
+            frame_stride = (int64_t)fbytes;
+        }
         dframes = (const uint8_t *)c->stage_frames.p;
         if (has_prev0) {
             rc = ensure(c, c->stage_prev, (size_t)h * row_stride);

@@ -167,11 +167,17 @@ class Engine:
             pp = prev0.ptr if prev0 is not None else None
             return (frames.ptr, pp, N.VQA_MEM_DEVICE, frames.n, frames.h, frames.w, frames.frame_stride,
                     frames.row_stride, (frames, prev0))
-        arr = np.ascontiguousarray(frames, dtype=np.uint8)
+        arr = np.asarray(frames)
+        if arr.dtype != np.uint8:
+            arr = arr.astype(np.uint8)
         if arr.ndim == 3:
             arr = arr[None]
         if arr.ndim != 4 or arr.shape[3] != 3:
             raise ValueError("frames must be uint8 [n,h,w,3] packed BGR")
+        # a strided selection of whole frames (clip[k-1::k]) is passed as is: frame_stride does the stepping
+        h_, w_ = arr.shape[1], arr.shape[2]
+        if not (arr.strides[1:] == (w_ * 3, 3, 1) and (arr.shape[0] == 1 or arr.strides[0] >= h_ * w_ * 3)):
+            arr = np.ascontiguousarray(arr)
         keep = [arr]
         pp = None
         if prev0 is not None:
@@ -181,7 +187,8 @@ class Engine:
             keep.append(p0)
             pp = p0.ctypes.data
         n, h, w, _ = arr.shape
-        return (arr.ctypes.data, pp, N.VQA_MEM_HOST, n, h, w, h * w * 3, w * 3, keep)
+        fstride = arr.strides[0] if n > 1 else h * w * 3
+        return (arr.ctypes.data, pp, N.VQA_MEM_HOST, n, h, w, fstride, w * 3, keep)
 
     def complexity_submit(self, frames, prev0=None, mask=N.M_ALL, params=None):
         fp, pp, kind, n, h, w, fs, rs, keep = self._frames_args(frames, prev0)

@@ -122,3 +122,17 @@ def test_y4m_quality_and_pipeline_row(tmp_path):
     assert m_ref["Resolution (px)"] == "104x72" and "PSNR" in m_ref and "SSIM" in m_ref
     rows = list(csv.reader(open(str(tmp_path / "a.csv"))))
     assert len(rows) == 3 and rows[0][0] == "Bitrate (kbps)"
+
+
+def test_device_resident_clip_with_interval():
+    """A clip that already lives in HBM, frame_interval > 1: the selected frames are a strided view
+    (frame_stride = interval * frame bytes), no gather copy; same tuple as the host path."""
+    from rtvqa_amd import complexity_metrics as cm
+    fr = _clip(37, 96, 128, seed=7)
+    dev = cm.get_engine().upload(fr)
+    a = cm.calculate_average_scene_complexity(fr, 64, 48, frame_interval=5, batch_size=3)
+    b = cm.calculate_average_scene_complexity(dev, 64, 48, frame_interval=5, batch_size=3)
+    for x, y in zip(a, b):
+        assert (np.isnan(x) and np.isnan(y)) or x == y
+    want = pl.calculate_average_scene_complexity(list(fr), 64, 48, frame_interval=5, dct_mode="full")
+    assert _close(a[1], want[1]) and a[3] == want[3] and _close(a[6], want[6]) and a[0] == want[0]
