@@ -307,11 +307,11 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
       temporal                   : T-2 samples (S_1->S_2 ... ; :533-537)
     """
     fr = _open_frames(video)
-    eng = engine or get_engine()
     idx = selected_indices(_num_frames(fr), frame_interval)
     out = {k: [] for k in ("motion", "dct", "hist", "edge", "color", "temporal")}
-    if len(idx) < 2:
+    if len(idx) < 2:  # unopenable / too short: empty series, as the reference's empty pair list (:95-97)
         return out
+    eng = engine or get_engine()
     params = eng.make_params(resize=(resize_width, resize_height), dct_mode=dct_mode)
     sel = idx[1:]
     prev_i = idx[0]

@@ -94,3 +94,13 @@ def test_bad_sources_raise_like_reference():
         cm.validate_video_path("clip.txt")
     with pytest.raises(NotImplementedError):
         cm.process_orb_frame_for_parallel(np.zeros((8, 8, 3), np.uint8))
+
+
+def test_empty_and_too_short_clips_need_no_device():
+    """Unopenable video -> [] -> np.mean([]) = NaN in the reference (:56-58, :95-97, :302-309); temporal 0.0 (:541).
+    These paths never reach a kernel, so they behave the same on a machine without a GPU."""
+    for clip in (np.zeros((0, 8, 8, 3), np.uint8), np.zeros((15, 8, 8, 3), np.uint8), "/nonexistent/clip.npy"):
+        out = cm.calculate_average_scene_complexity(clip, 64, 64, frame_interval=10)
+        assert len(out) == 8
+        assert all(math.isnan(out[i]) for i in (0, 1, 2, 3, 4, 5)) and out[6] == 0.0
+    assert cm.read_frame_pairs(np.zeros((15, 8, 8, 3), np.uint8), 10) == []
