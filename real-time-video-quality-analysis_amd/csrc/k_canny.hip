@@ -3,13 +3,13 @@
 // Reference function replaced: process_edge_frame, complexity_metrics.py:477-504
 //   cv2.Canny(gray, 100, 200) (aperture 3, L1 gradient) -> np.sum(edges > 0)
 //
-// Stage 1 (k_canny_nms): 64x32 tile per workgroup.  Gray tile + 2-pixel
-//   replicated halo staged in LDS, Sobel 3x3 + L1 magnitude for the tile + 1
-//   halo (magnitude outside the image = 0, as OpenCV's zero-bordered buffer),
-//   NMS with the TG22 fixed-point sector test, double threshold.  Writes a
-//   1 B/px state map: 0 none, 1 weak candidate, 2 edge.
-//   The result leaves the kernel as two BIT-PLANES (strong, weak), one u64 per
-//   64 pixels, assembled with __ballot: 2 x P/8 bytes instead of a P-byte map.
+// Stage 1 — gradient, non-maximum suppression, double threshold.  Output: two BIT-PLANES (edge,
+//   weak candidate), one u64 per 64 pixels, 2 x P/8 bytes instead of a P-byte map.
+//   k_canny_nms2 (default): register-rolling, 4 pixels per lane, packed 16-bit Sobel, no LDS (see below).
+//   k_canny_nms  (VQA_NMS_VARIANT=1, the first version, kept for A/B): 64x32 tile per workgroup, gray
+//   tile + 2-pixel replicated halo staged in LDS, magnitudes through LDS, words built with __ballot.
+//   Both: Sobel 3x3 on replicated borders, L1 magnitude = 0 outside the image (OpenCV's zero-bordered
+//   buffer), TG22 fixed-point sector test.
 // Stage 2 (k_canny_hyst_*): 8-connected hysteresis as an iterate-to-fixpoint on
 //   64x64-pixel tiles held ENTIRELY IN REGISTERS: lane r owns row r as a u64.
 //   One step = vertical neighbours by wave shuffles, 3-wide dilation by shifts,
@@ -17,8 +17,10 @@
 //   so a horizontal chain of any length is absorbed in ONE step.  Promotion is
 //   monotone (weak -> edge only), so the fixpoint is unique and independent of
 //   scheduling: the count is bit-exact with OpenCV's sequential stack walk.
-//   Tiles whose border changed enqueue their neighbours (dedup flag + atomic
-//   append); later rounds run over that compact list with a small fixed grid.
+//   A tile re-enqueues a neighbour only when one of the neighbour's candidates touches a pixel it
+//   promoted (dedup flag + atomic append into per-frame lists).  Round 0 = every tile, rounds 1-4 = the
+//   lists on a wide grid, then one persistent workgroup per frame runs its frame's remaining rounds with
+//   an agent-scope release/acquire between rounds: the host never waits inside the fixpoint.
 //
 // Roofline: HBM, P + P/4 (+ P/4 per hysteresis pass over live tiles) bytes per frame.
 #include "vqa_dev.hpp"
