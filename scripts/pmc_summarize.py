@@ -10,7 +10,8 @@ out = {"tag": tag, "frames_per_launch": frames, "unit": "bytes per launch",
        "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md §HBM)", "kernels": {}}
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (tag, ctr), "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (tag, ctr), "*", "*counter_collection.csv")),
+            key=os.path.getmtime)  # gpurun_out accumulates: take the newest pass
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("vqa::", "")
