@@ -6,9 +6,12 @@
 //     Tt = C_w . X^T         (w x h)      X = gray, or prev - curr (linearity)
 //     Yt = Tt . C_h^T        (w x h)      reduced on the fly: sum Y^2 or sum |Y|
 //
-// This is the PARITY mode for small planes; it is O(P (H + W)) flops and is not
-// the throughput path (the 8x8 block kernel is).  At 64x64 the whole transform
-// is 1 MFLOP per frame.
+// This is the PARITY mode: O(P (H + W)) flops, not the throughput path (the 8x8 block kernel is).  At
+// 64x64 the whole transform is 1 MFLOP per frame and runs on the vector ALUs (k_gemm_nt).  At native
+// resolution (1080p = 12.4 GFLOP per frame pair) the two products are the one truly
+// dense contraction of this code base, so planes of >= 128 x 128 go through k_gemm_nt_mfma: 128x128x16
+// LDS-tiled blocks on v_mfma_f32_32x32x2_f32 — exact fp32 (a k-ordered fmaf chain), so the result keeps
+// the 1e-4 parity bar, at the matrix pipe's rate instead of the vector ALUs'.
 #include "vqa_dev.hpp"
 #include "vqa_kernels.hpp"
 
@@ -67,6 +70,125 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const float *__restrict__ A, in
     }
 }
 
+// ---------------------------------------------------------------------------
+// out[M x N] = A[M x K] . B[N x K]^T on the matrix cores, fp32 in / fp32 accumulate.
+// Block tile 128 x 128, K step 16; 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32
+// (4 x 16 accumulator VGPRs).  Operand map of v_mfma_f32_32x32x2_f32: lane l holds A[i = l & 31][k = l >> 5]
+// and B[k = l >> 5][j = l & 31]; C/D: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// LDS tiles are k-major [16][130]: the fragment reads are 32 consecutive floats per half-wave and the
+// transposing stores (8 k-values of one row per thread) hit 32 distinct banks (pitch 130 = 2 mod 32).
+// grid = (ceil(N/128), ceil(M/128), n_frames)
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int GB = 128, GK = 16, GP_ = 130;
+
+template <int BMODE>
+__device__ __forceinline__ void load8(const void *__restrict__ Bv, const void *__restrict__ B2v, int64_t base, int k,
+                                      int K, bool row_ok, float v[8])
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = 0.f;
+    if (!row_ok) return;
+    if (BMODE == B_F32) {
+        const float *p = (const float *)Bv + base + k;
+        if (k + 8 <= K && (((uintptr_t)p) & 15) == 0) {
+            const float4 a = ((const float4 *)p)[0], b = ((const float4 *)p)[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (k + j < K) v[j] = p[j];
+        }
+    } else {
+        const uint8_t *p = (const uint8_t *)Bv + base + k;
+        const uint8_t *q = BMODE == B_U8_DIFF ? (const uint8_t *)B2v + base + k : p;
+        if (k + 8 <= K && ((((uintptr_t)p) | ((uintptr_t)q)) & 7) == 0) {
+            const uint64_t pw = *(const uint64_t *)p, qw = BMODE == B_U8_DIFF ? *(const uint64_t *)q : 0ull;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int pv = (int)((pw >> (8 * j)) & 0xff), qv = (int)((qw >> (8 * j)) & 0xff);
+                v[j] = BMODE == B_U8_DIFF ? (float)(qv - pv) : (float)pv;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (k + j < K) v[j] = BMODE == B_U8_DIFF ? (float)((int)q[j] - (int)p[j]) : (float)p[j];
+        }
+    }
+}
+
+template <int BMODE, int RED>
+__global__ __launch_bounds__(256) void k_gemm_nt_mfma(const float *__restrict__ A, int64_t a_frame_stride, int lda,
+                                                      const void *__restrict__ Bv, const void *__restrict__ B2v,
+                                                      int64_t b_frame_stride, int ldb, int M, int N, int K,
+                                                      float *__restrict__ out, int64_t out_frame_stride, int ldo,
+                                                      double *__restrict__ partials)
+{
+    __shared__ float As[GK * GP_], Bs[GK * GP_];
+    __shared__ double red[4];
+    const int f = blockIdx.z;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int m0 = blockIdx.y * GB, n0 = blockIdx.x * GB;
+    const int lrow = t >> 1, lk = (t & 1) * 8; // staging role: one tile row, 8 consecutive k
+    const float *Af = A + (int64_t)f * a_frame_stride;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int64_t abase = (int64_t)(m0 + lrow) * lda;
+    const int64_t bbase = (int64_t)f * b_frame_stride + (int64_t)(n0 + lrow) * ldb;
+    const bool a_ok = m0 + lrow < M, b_ok = n0 + lrow < N;
+    float av[8], bv[8];
+    load8<B_F32>(Af, nullptr, abase, lk, K, a_ok, av);
+    load8<BMODE>(Bv, B2v, bbase, lk, K, b_ok, bv);
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        __syncthreads(); // previous step's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            As[(lk + j) * GP_ + lrow] = av[j];
+            Bs[(lk + j) * GP_ + lrow] = bv[j];
+        }
+        __syncthreads();
+        if (k0 + GK < K) { // next step's operands travel while this step's MFMAs run
+            load8<B_F32>(Af, nullptr, abase, k0 + GK + lk, K, a_ok, av);
+            load8<BMODE>(Bv, B2v, bbase, k0 + GK + lk, K, b_ok, bv);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const int kr = (kk + (lane >> 5)) * GP_ + (lane & 31);
+            const float a0 = As[kr + wm * 64], a1 = As[kr + wm * 64 + 32];
+            const float b0 = Bs[kr + wn * 64], b1 = Bs[kr + wn * 64 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    double sum = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (m < M && n < N) {
+                    const float v = acc[i][j][r];
+                    if (RED == RED_STORE) out[(int64_t)f * out_frame_stride + (int64_t)m * ldo + n] = v;
+                    else sum += RED == RED_SQ ? (double)(v * v) : (double)fabsf(v);
+                }
+            }
+    if (RED != RED_STORE) {
+        const double tsum = block_sum(sum, red);
+        if (t == 0) partials[((int64_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tsum;
+    }
+}
+
 __global__ void k_full_finalize(const double *__restrict__ pe, const double *__restrict__ pt, int tiles, int n,
                                 vqa_frame_metrics *__restrict__ res, int write_energy, int write_temporal,
                                 int first_has_prev)
@@ -95,26 +217,33 @@ void launch_dct_full(hipStream_t st, const uint8_t *planes, int pitch, int64_t p
 {
     if (n <= 0 || (!energy && !temporal)) return;
     dim3 block(256);
-    dim3 g1((h + 15) / 16, (w + 15) / 16, n); // Tt: M = w, N = h, K = w
-    dim3 g2((h + 15) / 16, (w + 15) / 16, n); // Yt: M = w, N = h, K = h
-    const int tiles = g2.x * g2.y;
+    const bool mfma = h >= 128 && w >= 128;
+    const int T = mfma ? GB : 16;
+    dim3 g((h + T - 1) / T, (w + T - 1) / T, n); // both products: M = w, N = h  (K = w, then K = h)
+    const int tiles = g.x * g.y;
     const uint8_t *curr = planes + plane_stride; // frame f -> slot f+1
     const uint8_t *prev = planes;                // frame f -> slot f
+#define GEMM(KERNEL, BM, RD, ...) hipLaunchKernelGGL((KERNEL<BM, RD>), g, block, 0, st, __VA_ARGS__)
+#define BOTH(BM, RD, ...)                                                                                             \
+    do {                                                                                                              \
+        if (mfma) GEMM(k_gemm_nt_mfma, BM, RD, __VA_ARGS__);                                                          \
+        else GEMM(k_gemm_nt, BM, RD, __VA_ARGS__);                                                                    \
+    } while (0)
     if (energy) {
-        hipLaunchKernelGGL((k_gemm_nt<B_U8, RED_STORE>), g1, block, 0, st, cw, (int64_t)0, w, (const void *)curr,
-                           (const void *)nullptr, plane_stride, pitch, w, h, w, scratch, (int64_t)w * h, h,
-                           (double *)nullptr);
-        hipLaunchKernelGGL((k_gemm_nt<B_F32, RED_SQ>), g2, block, 0, st, scratch, (int64_t)w * h, h, (const void *)ch,
-                           (const void *)nullptr, (int64_t)0, h, w, h, h, (float *)nullptr, (int64_t)0, 0, pe);
+        BOTH(B_U8, RED_STORE, cw, (int64_t)0, w, (const void *)curr, (const void *)nullptr, plane_stride, pitch, w, h, w,
+             scratch, (int64_t)w * h, h, (double *)nullptr);
+        BOTH(B_F32, RED_SQ, scratch, (int64_t)w * h, h, (const void *)ch, (const void *)nullptr, (int64_t)0, h, w, h, h,
+             (float *)nullptr, (int64_t)0, 0, pe);
     }
     if (temporal) {
         // B = prev - curr  (Bv = curr, B2v = prev)
-        hipLaunchKernelGGL((k_gemm_nt<B_U8_DIFF, RED_STORE>), g1, block, 0, st, cw, (int64_t)0, w, (const void *)curr,
-                           (const void *)prev, plane_stride, pitch, w, h, w, scratch, (int64_t)w * h, h,
-                           (double *)nullptr);
-        hipLaunchKernelGGL((k_gemm_nt<B_F32, RED_ABS>), g2, block, 0, st, scratch, (int64_t)w * h, h, (const void *)ch,
-                           (const void *)nullptr, (int64_t)0, h, w, h, h, (float *)nullptr, (int64_t)0, 0, pt);
+        BOTH(B_U8_DIFF, RED_STORE, cw, (int64_t)0, w, (const void *)curr, (const void *)prev, plane_stride, pitch, w, h, w,
+             scratch, (int64_t)w * h, h, (double *)nullptr);
+        BOTH(B_F32, RED_ABS, scratch, (int64_t)w * h, h, (const void *)ch, (const void *)nullptr, (int64_t)0, h, w, h, h,
+             (float *)nullptr, (int64_t)0, 0, pt);
     }
+#undef BOTH
+#undef GEMM
     hipLaunchKernelGGL(k_full_finalize, dim3((n + 63) / 64), dim3(64), 0, st, pe, pt, tiles, n, res, (int)energy,
                        (int)temporal, (int)first_has_prev);
 }

@@ -109,7 +109,8 @@ def test_dct8_constant_frames_known_answer(engine):
     assert rec[0]["temporal_dct_l1"] == 0.0
 
 
-@pytest.mark.parametrize("h,w,rw,rh", [(270, 480, 64, 64), (64, 64, 64, 64), (90, 120, 40, 24)])
+@pytest.mark.parametrize("h,w,rw,rh", [(270, 480, 64, 64), (64, 64, 64, 64), (90, 120, 40, 24),
+                                       (270, 480, 480, 270), (300, 500, 200, 150), (540, 960, 960, 540)])
 def test_dct_full_frame_parity_mode(engine, h, w, rw, rh):
     """config.json's own case: full-frame cv2.dct semantics on the resized plane (:363, :574-579)."""
     from rtvqa_amd import _native as N
@@ -121,9 +122,12 @@ def test_dct_full_frame_parity_mode(engine, h, w, rw, rh):
         p = co.resize_linear(co.bgr2gray(fr[i]), rw, rh)
         assert _rel(rec[i]["dct_energy"], co.dct_energy_full(a)) < RTOL
         assert _rel(rec[i]["temporal_dct_l1"], co.temporal_dct_full(p, a)) < RTOL
-    # AUTO picks FULL for planes up to 128x128
+    # AUTO picks FULL for planes up to 128x128, the 8x8 block metric above that
     rec2 = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_TEMPORAL_DCT, resize=(rw, rh))
-    assert rec2[0]["temporal_dct_l1"] == rec[0]["temporal_dct_l1"]
+    if rw * rh <= 128 * 128:
+        assert rec2[0]["temporal_dct_l1"] == rec[0]["temporal_dct_l1"]
+    else:
+        assert rec2[0]["temporal_dct_l1"] != rec[0]["temporal_dct_l1"]  # a different metric
 
 
 # ---------------------------------------------------------------------------
