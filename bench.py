@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--pixfmt", default="bgr24", choices=["bgr24", "yuv420p"],
                     help="planes PSNR/SSIM compare: bgr24 (default: B,G,R of the packed frames) or yuv420p (Y + "
                          "quarter-size U,V derived from the same frames: what FFmpeg compares for an H.264 clip)")
+    ap.add_argument("--dct-mode", default="block8", choices=["block8", "full"],
+                    help="block8 (default, north_star's 8x8 DCT) or full (the reference's full-frame cv2.dct, on fp32 MFMA)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the rank logic)")
     args = ap.parse_args()
@@ -175,7 +177,7 @@ def main():
     ref_b, dist_b, prev0 = ref_all.slice(1, B + 1), dist_all.slice(1, B + 1), dist_all.frame(0)
 
     mask = N.M_ALL if full else (N.M_DCT | N.M_TEMPORAL_DCT)
-    params = eng.make_params(dct_mode=N.DCT_BLOCK8)
+    params = eng.make_params(dct_mode=N.DCT_BLOCK8 if args.dct_mode == "block8" else N.DCT_FULL)
     planes = bgr_planes(h, w)
     if yuv:  # quality kernels read the planar streams; the complexity kernels still read the BGR frames
         planes = yuv420p_planes(h, w)
@@ -252,7 +254,12 @@ def main():
         tot = sum(ms for ms, _ in prof.values()) or 1.0
         for name, (ms, _) in prof.items():
             kernels[name]["share_of_kernel_time"] = round(ms / tot, 4)
-        dom = max((k for k in prof if k in alg_bytes), key=lambda k: prof[k][0])
+        mfma_flops = {"k_dct_full(gemm_nt x4)": 2 * 2.0 * (w * w * h + h * h * w) * B}  # energy + temporal, 2 products each
+        for name, fl in mfma_flops.items():
+            if name in kernels:
+                tf = fl / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
+                kernels[name].update({"flops": fl, "TFLOPps": round(tf, 1), "frac_mfma_f32": round(tf / 157.3, 4)})
+        dom = max((k for k in prof if k in alg_bytes or k in mfma_flops), key=lambda k: prof[k][0])
         # HBM traffic per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of THIS
         # command (scripts/gpu_pmc.sh), corrected as the guide prescribes and committed under profiles/
         traffic = None
@@ -262,11 +269,16 @@ def main():
             for kname, ent in pmc["kernels"].items():
                 if kname.split("<")[0] == dom:
                     traffic = int(ent["hbm_bytes"] * B / pmc["frames_per_launch"])
-        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "alg_bytes": alg_bytes[dom],
-                "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"
-                        + ("; k_ssim_gauss is VALU-bound by construction: 79% VALU-busy at 0.66 TB/s (DESIGN.md section 5)"
-                           if dom == "k_ssim_gauss" else "")}
+        if dom in mfma_flops:
+            roof = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": kernels[dom]["frac_mfma_f32"], "traffic": None,
+                    "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = flops per launch / mean HIP-event duration"}
+        else:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "alg_bytes": alg_bytes[dom],
+                    "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"
+                            + ("; k_ssim_gauss is VALU-bound by construction: 79% VALU-busy at 0.66 TB/s "
+                               "(DESIGN.md section 5)" if dom == "k_ssim_gauss" else "")}
         line = {
             "metric": "frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -275,7 +287,7 @@ def main():
                     % synth.GENERATOR_VERSION,
             "config": {"workload": wl["name"] if args.ssim_mode == "gauss" else
                        wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"), "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams,
-                       "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "parallelism": "1 stream/GPU x%d" % world},
+                       "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode, "parallelism": "1 stream/GPU x%d" % world},
             "roofline": roof, "kernels": kernels,
         }
         if cpu_line is not None:
