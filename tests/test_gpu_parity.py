@@ -368,6 +368,61 @@ def test_full_size_2160p_parity(engine):
     _check_quality(engine, g[None], gd, gray_planes(h, w), "ffmpeg")
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_geometries_all_kernels(engine, seed):
+    """Ragged, odd and tiny frame geometries drawn at random: every kernel against the oracle."""
+    from rtvqa_amd import _native as N
+    from rtvqa_amd import synth
+    from rtvqa_amd.engine import bgr_planes
+    r = _rng(1000 + seed)
+    h, w = int(r.integers(16, 180)), int(r.integers(16, 300))
+    kind = "natural" if seed % 2 else "noise"
+    fr = _frames(kind, 3, h, w, seed=seed)
+    lo, hi = (100, 200) if seed % 3 else (15, 45)
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8, canny=(lo, hi),
+                            sad_range=int(r.integers(0, 8)))
+    for i in range(2):
+        g, gp = co.bgr2gray(fr[i + 1]), co.bgr2gray(fr[i])
+        assert (rec[i]["hist_gray"] == co.hist_u8(g)).all(), (h, w)
+        for c in range(3):
+            assert (rec[i]["hist_bgr"][c] == co.hist_u8(fr[i + 1], offset=c, step=3)).all(), (h, w)
+        e, l1, _ = co.dct8x8(gp, g)
+        assert _rel(rec[i]["dct_energy"], e) < RTOL and _rel(rec[i]["temporal_dct_l1"], max(l1, 1e-9)) < RTOL or l1 == 0
+        cnt, strong, weak = co.canny(g, lo, hi)
+        assert (int(rec[i]["edge_strong"]), int(rec[i]["edge_weak"]), int(rec[i]["edge_count"])) == (strong, weak, cnt), (h, w)
+    dist = synth.distort(fr)
+    if h >= 11 and w >= 11:
+        _check_quality(engine, fr, dist, bgr_planes(h, w), "gauss")
+    if h >= 8 and w >= 8:
+        _check_quality(engine, fr, dist, bgr_planes(h, w), "ffmpeg")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_geometries_sad_and_resize(engine, seed):
+    from rtvqa_amd import _native as N
+    r = _rng(2000 + seed)
+    h, w = int(r.integers(16, 200)), int(r.integers(16, 330))
+    rng_ = int(r.integers(0, 8))
+    fr = _frames("natural", 3, h, w, seed=50 + seed)
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_MOTION, sad_range=rng_)
+    for i in range(2):
+        nb, sad, hist = co.block_sad(co.bgr2gray(fr[i]), co.bgr2gray(fr[i + 1]), rng_)
+        assert int(rec[i]["sad_blocks"]) == nb and int(rec[i]["sad_sum"]) == sad and (rec[i]["mv_d2_hist"] == hist).all(), (h, w, rng_)
+    rw, rh = int(r.integers(8, 200)), int(r.integers(8, 150))
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_GRAY_HIST | N.M_COLOR_HIST | N.M_EDGE | N.M_DCT | N.M_TEMPORAL_DCT,
+                            resize=(rw, rh), dct_mode=N.DCT_BLOCK8)
+    for i in range(2):
+        a = co.resize_linear(co.bgr2gray(fr[i + 1]), rw, rh)
+        p = co.resize_linear(co.bgr2gray(fr[i]), rw, rh)
+        rb = co.resize_linear(fr[i + 1], rw, rh)
+        b = co.bgr2gray(rb)
+        assert (engine.debug_plane(0, i, rh, rw) == a).all() and (engine.debug_plane(1, i, rh, rw) == b).all(), (h, w, rw, rh)
+        assert (rec[i]["hist_gray"] == co.hist_u8(b)).all()
+        assert int(rec[i]["edge_count"]) == co.canny(b, 100, 200)[0]
+        e, l1, _ = co.dct8x8(p, a)
+        assert _rel(rec[i]["dct_energy"], e) < RTOL and (l1 == 0 or _rel(rec[i]["temporal_dct_l1"], l1) < RTOL)
+
+
 def test_argument_errors(engine):
     from rtvqa_amd import _native as N
     fr = np.zeros((1, 32, 32, 3), np.uint8)
