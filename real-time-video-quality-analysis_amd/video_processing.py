@@ -191,3 +191,45 @@ def extract_metrics_from_logs(psnr_log, ssim_log, vmaf_log, video_file, crf, bit
             if match:
                 metrics["SSIM"] = float(match.group(1))
     return metrics
+
+
+def load_config(config_file):
+    """video_processing.py:71-85 — JSON config, validated; same keys as the reference's config.json."""
+    import json
+    with open(config_file, "r") as f:
+        config = json.load(f)
+    validate_config(config)
+    return config
+
+
+def validate_config(config):
+    """video_processing.py:87-98 — same range checks, same messages."""
+    if not (1 <= config.get("crf", 23) <= 51):
+        raise ValueError("CRF value must be between 1 and 51.")
+    if config.get("resize_width", 0) <= 0 or config.get("resize_height", 0) <= 0:
+        raise ValueError("Resize dimensions must be positive integers.")
+    if config.get("frame_interval", 10) <= 0:
+        raise ValueError("Frame interval must be a positive integer.")
+    if not isinstance(config.get("num_workers", (os.cpu_count() or 2) // 2), int):
+        raise ValueError("num_workers must be an integer.")
+
+
+def main(argv=None):
+    """video_processing.py:300-321 with decoded streams instead of a container + encode step:
+        python -m rtvqa_amd.video_processing config.json input.npy encoded.npy [--csv out.csv]"""
+    import argparse
+    ap = argparse.ArgumentParser(description="Quality + complexity metrics of an (input, encoded) stream pair -> CSV row.")
+    ap.add_argument("config_file")
+    ap.add_argument("input_video", help="reference stream: .npy [N,H,W,3] BGR")
+    ap.add_argument("encoded_video", help="distorted stream, same geometry")
+    ap.add_argument("--csv", default="video_quality_data.csv")
+    ap.add_argument("--column-order", default="reference", choices=["reference", "fixed"])
+    a = ap.parse_args(argv)
+    m = process_video_and_extract_metrics(a.input_video, a.encoded_video, load_config(a.config_file), csv_file=a.csv,
+                                          column_order=a.column_order)
+    print(m)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

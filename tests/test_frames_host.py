@@ -37,3 +37,17 @@ def test_csv_writer_header_once(tmp_path):
     vp.thread_safe_update_csv({"PSNR": 48.13, "SSIM": 0.9}, p)
     rows = list(csv.reader(open(p)))
     assert rows[0] == ["PSNR", "SSIM"] and len(rows) == 3 and rows[2] == ["48.13", "0.9"]
+
+
+def test_config_loader_matches_reference_checks(tmp_path):
+    import json
+    good = {"crf": 23, "vmaf_model_path": None, "resize_width": 64, "resize_height": 64, "frame_interval": 10}
+    p = tmp_path / "config.json"
+    p.write_text(json.dumps(good))
+    assert vp.load_config(str(p)) == good
+    for bad, msg in (({**good, "crf": 0}, "CRF"), ({**good, "resize_width": 0}, "Resize"),
+                     ({**good, "frame_interval": 0}, "Frame interval"), ({**good, "num_workers": 2.5}, "num_workers")):
+        with pytest.raises(ValueError, match=msg):
+            vp.validate_config(bad)
+    with pytest.raises(FileNotFoundError):
+        vp.load_config(str(tmp_path / "missing.json"))
