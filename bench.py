@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--pixfmt", default="bgr24", choices=["bgr24", "yuv420p"],
                     help="planes PSNR/SSIM compare: bgr24 (default: B,G,R of the packed frames) or yuv420p (Y + "
                          "quarter-size U,V derived from the same frames: what FFmpeg compares for an H.264 clip)")
+    ap.add_argument("--content", default="natural", choices=["natural", "noise"],
+                    help="synthetic stream: s_natural (default) or s_noise (max-entropy bins, worst case for Canny fan-out)")
     ap.add_argument("--dct-mode", default="block8", choices=["block8", "full"],
                     help="block8 (default, north_star's 8x8 DCT) or full (the reference's full-frame cv2.dct, on fp32 MFMA)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -163,7 +165,8 @@ def main():
     chunk = 32
     for a in range(0, B + 1, chunk):
         n = min(chunk, B + 1 - a)
-        r = synth.s_natural(n, h, w, seed=1234, stream_id=rank, t0=a)
+        r = (synth.s_natural(n, h, w, seed=1234, stream_id=rank, t0=a) if args.content == "natural"
+             else synth.s_noise(n, h, w, seed=1234 + a, stream_id=rank))
         d = synth.distort(r, t0=a)
         N.check(eng.lib.vqa_copy_h2d(eng.ctx, ref_buf.ptr + a * fbytes, r.ctypes.data, r.nbytes), "h2d", eng.ctx)
         N.check(eng.lib.vqa_copy_h2d(eng.ctx, dist_buf.ptr + a * fbytes, d.ctypes.data, d.nbytes), "h2d", eng.ctx)
@@ -283,8 +286,8 @@ def main():
             "metric": "frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->f32 (SSE/bins/SAD exact int)",
-            "data": "synthetic (synth.s_natural v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
-                    % synth.GENERATOR_VERSION,
+            "data": "synthetic (synth.s_%s v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
+                    % (args.content, synth.GENERATOR_VERSION),
             "config": {"workload": wl["name"] if args.ssim_mode == "gauss" else
                        wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"), "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams,
                        "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode, "parallelism": "1 stream/GPU x%d" % world},
