@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of kernel variants (env VQA_SSIM_VARIANT / VQA_DCT_VARIANT), one child process per
-variant so each gets a fresh library state.  usage: python scripts/kbench.py ssim 0 1 2 3 4 5 | dct 0 1 2"""
+variant so each gets a fresh library state.  usage: python scripts/kbench.py ssim 0 1 2 3 4 | dct 0 1 2 4 5 | dcte 0 1 2 4 5"""
 import os
 import subprocess
 import sys
@@ -26,6 +26,8 @@ def child(kind):
             eng.profile_read(reset=True)
         if kind == "ssim":
             eng.quality(dr.slice(1, B + 1), dd.slice(1, B + 1), bgr_planes(h, w), N.SSIM_GAUSS)
+        elif kind == "dcte":  # energy only (the c2 workload's launch)
+            eng.complexity(dd.slice(1, B + 1), prev0=dd.frame(0), mask=N.M_DCT, dct_mode=N.DCT_BLOCK8)
         else:
             eng.complexity(dd.slice(1, B + 1), prev0=dd.frame(0), mask=N.M_DCT | N.M_TEMPORAL_DCT, dct_mode=N.DCT_BLOCK8)
     prof = eng.profile_read()
@@ -33,8 +35,9 @@ def child(kind):
         if k.startswith("k_ssim") or k.startswith("k_dct8"):
             per = ms / cnt
             npl = 3 if k.startswith("k_ssim") else 1
+            nb = 1 if kind == "dcte" else 2  # algorithmic bytes per pixel
             print("  %-16s %.4f ms/launch (%d frames x %d planes) = %.3f us/frame-plane  %.0f GB/s" %
-                  (k, per, B, npl, per * 1e3 / B / npl, 2 * h * w * B * npl / (per * 1e-3) / 1e9), flush=True)
+                  (k, per, B, npl, per * 1e3 / B / npl, nb * h * w * B * npl / (per * 1e-3) / 1e9), flush=True)
 
 
 if __name__ == "__main__":
