@@ -397,6 +397,41 @@ def test_random_geometries_all_kernels(engine, seed):
         _check_quality(engine, fr, dist, bgr_planes(h, w), "ffmpeg")
 
 
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 9), (9, 1), (2, 2), (3, 5), (7, 7), (9, 9), (15, 17), (1, 300), (300, 1),
+                                 (2, 129), (5, 64)])
+def test_tiny_frames_all_complexity_kernels(engine, h, w):
+    """Frames smaller than a DCT block, a SAD block, a Sobel window or a 4-pixel lane group."""
+    from rtvqa_amd import _native as N
+    fr = _rng(h * 1000 + w).integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+    fr[2, :, : (w + 1) // 2] = 255  # a hard step so tiny frames still carry edges
+    fr[2, :, (w + 1) // 2:] = 0
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8, canny=(20, 60))
+    for i in range(2):
+        g, gp = co.bgr2gray(fr[i + 1]), co.bgr2gray(fr[i])
+        assert (rec[i]["hist_gray"] == co.hist_u8(g)).all()
+        for c in range(3):
+            assert (rec[i]["hist_bgr"][c] == co.hist_u8(fr[i + 1], offset=c, step=3)).all()
+        assert int(rec[i]["sum_gray2"]) == int((g.astype(np.int64) ** 2).sum())
+        e, l1, _ = co.dct8x8(gp, g)
+        assert e == 0 or _rel(rec[i]["dct_energy"], e) < RTOL
+        assert l1 == 0 or _rel(rec[i]["temporal_dct_l1"], l1) < RTOL
+        cnt, strong, weak, emap = co.canny(g, 20, 60, want_map=True)
+        assert (int(rec[i]["edge_strong"]), int(rec[i]["edge_weak"]), int(rec[i]["edge_count"])) == (strong, weak, cnt)
+        assert ((engine.debug_plane(2, i, h, w) != 0) == (emap != 0)).all()
+        nb, sad, hist = co.block_sad(gp, g, 7)
+        assert (int(rec[i]["sad_sum"]), int(rec[i]["sad_blocks"])) == (sad, nb)
+        assert (rec[i]["mv_d2_hist"] == hist).all()
+    # full-frame DCT mode and the resize path on the same tiny frames
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_DCT | N.M_TEMPORAL_DCT | N.M_GRAY_HIST, dct_mode=N.DCT_FULL,
+                            resize=(6, 4))
+    for i in range(2):
+        p_, a_ = (co.resize_linear(co.bgr2gray(fr[i + k]), 6, 4) for k in (0, 1))
+        e, l1 = co.dct_energy_full(a_), co.temporal_dct_full(p_, a_)
+        assert e == 0 or _rel(rec[i]["dct_energy"], e) < RTOL
+        assert l1 == 0 or _rel(rec[i]["temporal_dct_l1"], l1) < RTOL
+        assert (rec[i]["hist_gray"] == co.hist_u8(co.bgr2gray(co.resize_linear(fr[i + 1], 6, 4)))).all()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_geometries_sad_and_resize(engine, seed):
     from rtvqa_amd import _native as N
