@@ -145,8 +145,10 @@ VQA_API void *vqa_stream(vqa_ctx *ctx);
 /* ---- complexity kernels (replaces process_in_batches over process_*_frame) - */
 /* frames: n packed BGR24 frames (what cv2.VideoCapture.read yields,
  * complexity_metrics.py:100), frame i at frames + i*frame_stride, rows of
- * 3*w bytes at row_stride.  prev0: the frame preceding frames[0] (same
- * geometry, same mem_kind) or NULL; frame i's "previous" is frame i-1.
+ * 3*w bytes at row_stride (>= 3*w: padded rows, or a region of interest
+ * inside larger frames; only the 3*w bytes of each row are ever read).
+ * prev0: the frame preceding frames[0] (same geometry, row_stride and
+ * mem_kind) or NULL; frame i's "previous" is frame i-1.
  * Asynchronous: returns once the work is enqueued.                           */
 VQA_API int vqa_complexity_submit(vqa_ctx *ctx, const uint8_t *frames, const uint8_t *prev0, int mem_kind,
                           int n, int h, int w, int64_t frame_stride, int64_t row_stride,

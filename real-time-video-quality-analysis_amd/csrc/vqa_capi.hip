@@ -340,7 +340,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     if (!c || !frames || n <= 0 || h <= 0 || w <= 0) return VQA_ERR_INVALID;
     if (mem_kind != VQA_MEM_HOST && mem_kind != VQA_MEM_DEVICE) return VQA_ERR_INVALID;
     if (!mask || (mask & ~VQA_M_ALL)) return VQA_ERR_INVALID;
-    if (row_stride < (int64_t)3 * w || frame_stride < row_stride * h) return VQA_ERR_INVALID;
+    if (row_stride < (int64_t)3 * w || frame_stride < row_stride * (h - 1) + (int64_t)3 * w) return VQA_ERR_INVALID;
     if (c->pend_c) return VQA_ERR_STATE;
     vqa_params P;
     if (params) P = *params; else vqa_default_params(&P);
@@ -364,25 +364,38 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     // ---- bring frames to the device if they are on the host
     const uint8_t *dframes = frames, *dprev = prev0;
     if (mem_kind == VQA_MEM_HOST) {
-        const size_t fbytes = (size_t)h * row_stride;
+        // The device copy is always compact (rows of 3w bytes): padded rows / a region of interest inside
+        // larger frames cross PCIe as a 2-D copy, so no byte outside the caller's rows is ever read.
+        const size_t rbytes = (size_t)3 * w, fbytes = rbytes * h;
+        const bool padded = (size_t)row_stride != rbytes;
         int rc = ensure(c, c->stage_frames, fbytes * n);
         if (rc) return rc;
-        if ((size_t)frame_stride == fbytes) {
+        if (!padded && (size_t)frame_stride == fbytes) {
             HIPCHK(c, hipMemcpyAsync(c->stage_frames.p, frames, fbytes * n, hipMemcpyHostToDevice, st));
         } else {
             // strided selection (every k-th frame of a clip): only the selected frames cross PCIe
-            for (int i = 0; i < n; i++)
-                HIPCHK(c, hipMemcpyAsync((uint8_t *)c->stage_frames.p + fbytes * i, frames + (int64_t)i * frame_stride,
-                                         fbytes, hipMemcpyHostToDevice, st));
-            frame_stride = (int64_t)fbytes;
+            for (int i = 0; i < n; i++) {
+                uint8_t *dst = (uint8_t *)c->stage_frames.p + fbytes * i;
+                const uint8_t *src = frames + (int64_t)i * frame_stride;
+                if (padded)
+                    HIPCHK(c, hipMemcpy2DAsync(dst, rbytes, src, (size_t)row_stride, rbytes, h, hipMemcpyHostToDevice, st));
+                else
+                    HIPCHK(c, hipMemcpyAsync(dst, src, fbytes, hipMemcpyHostToDevice, st));
+            }
         }
         dframes = (const uint8_t *)c->stage_frames.p;
         if (has_prev0) {
-            rc = ensure(c, c->stage_prev, (size_t)h * row_stride);
+            rc = ensure(c, c->stage_prev, fbytes);
             if (rc) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->stage_prev.p, prev0, (size_t)h * row_stride, hipMemcpyHostToDevice, st));
+            if (padded)
+                HIPCHK(c, hipMemcpy2DAsync(c->stage_prev.p, rbytes, prev0, (size_t)row_stride, rbytes, h,
+                                           hipMemcpyHostToDevice, st));
+            else
+                HIPCHK(c, hipMemcpyAsync(c->stage_prev.p, prev0, fbytes, hipMemcpyHostToDevice, st));
             dprev = (const uint8_t *)c->stage_prev.p;
         }
+        frame_stride = (int64_t)fbytes;
+        row_stride = (int64_t)rbytes;
     }
 
     int rc = ensure(c, c->res_dev, sizeof(vqa_frame_metrics) * (size_t)n);

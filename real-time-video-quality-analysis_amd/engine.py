@@ -56,6 +56,12 @@ class DeviceFrames:
         return DeviceFrames(self.ptr + a * self.frame_stride, b - a, self.h, self.w, self.frame_stride,
                             self.row_stride, owner=self._owner, channels=self.channels)
 
+    def roi(self, y0, y1, x0, x1):
+        """The window rows y0..y1, columns x0..x1 of every frame, in place (same memory, padded rows)."""
+        assert 0 <= y0 < y1 <= self.h and 0 <= x0 < x1 <= self.w
+        return DeviceFrames(self.ptr + y0 * self.row_stride + x0 * self.channels, self.n, y1 - y0, x1 - x0,
+                            self.frame_stride, self.row_stride, owner=self._owner, channels=self.channels)
+
 
 class DeviceBuffer:
     def __init__(self, engine, nbytes):
@@ -174,21 +180,30 @@ class Engine:
             arr = arr[None]
         if arr.ndim != 4 or arr.shape[3] != 3:
             raise ValueError("frames must be uint8 [n,h,w,3] packed BGR")
-        # a strided selection of whole frames (clip[k-1::k]) is passed as is: frame_stride does the stepping
+        # a strided selection of whole frames (clip[k-1::k]) and a region of interest (clip[:, y0:y1, x0:x1])
+        # are passed as they are: frame_stride / row_stride do the stepping
         h_, w_ = arr.shape[1], arr.shape[2]
-        if not (arr.strides[1:] == (w_ * 3, 3, 1) and (arr.shape[0] == 1 or arr.strides[0] >= h_ * w_ * 3)):
+        st = arr.strides
+        if not (st[2:] == (3, 1) and st[1] >= w_ * 3 and (arr.shape[0] == 1 or st[0] >= (h_ - 1) * st[1] + w_ * 3)):
             arr = np.ascontiguousarray(arr)
+        rstride = arr.strides[1] if h_ > 1 else w_ * 3
         keep = [arr]
         pp = None
         if prev0 is not None:
-            p0 = np.ascontiguousarray(prev0, dtype=np.uint8)
+            p0 = np.asarray(prev0, dtype=np.uint8)
             if p0.shape != arr.shape[1:]:
                 raise ValueError("prev0 must have the frames' geometry")
+            if not (p0.strides[1:] == (3, 1) and (h_ == 1 or p0.strides[0] == rstride)):
+                if rstride != w_ * 3:  # one row stride serves frames and prev0: fall back to compact copies
+                    arr = np.ascontiguousarray(arr)
+                    rstride = w_ * 3
+                    keep[0] = arr
+                p0 = np.ascontiguousarray(p0)
             keep.append(p0)
             pp = p0.ctypes.data
         n, h, w, _ = arr.shape
-        fstride = arr.strides[0] if n > 1 else h * w * 3
-        return (arr.ctypes.data, pp, N.VQA_MEM_HOST, n, h, w, fstride, w * 3, keep)
+        fstride = arr.strides[0] if n > 1 else max(h * rstride, 1)
+        return (arr.ctypes.data, pp, N.VQA_MEM_HOST, n, h, w, fstride, rstride, keep)
 
     def complexity_submit(self, frames, prev0=None, mask=N.M_ALL, params=None):
         fp, pp, kind, n, h, w, fs, rs, keep = self._frames_args(frames, prev0)

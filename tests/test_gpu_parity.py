@@ -458,6 +458,32 @@ def test_random_geometries_sad_and_resize(engine, seed):
         assert _rel(rec[i]["dct_energy"], e) < RTOL and (l1 == 0 or _rel(rec[i]["temporal_dct_l1"], l1) < RTOL)
 
 
+def test_region_of_interest_padded_rows(engine):
+    """row_stride > 3w: a window inside larger frames, host and device resident, odd (unaligned) origins.
+    The host window ends at the very last byte of its parent array, so any read past a row's 3w bytes
+    would leave the allocation."""
+    from rtvqa_amd import _native as N
+    big = _frames("natural", 4, 120, 200, seed=21)
+    dbig = engine.upload(big)
+    for (y0, y1, x0, x1) in [(7, 120, 13, 200), (0, 64, 0, 128), (31, 95, 5, 69), (1, 120, 1, 200)]:
+        sub = big[:, y0:y1, x0:x1]
+        want = engine.complexity(np.ascontiguousarray(sub[1:]), prev0=np.ascontiguousarray(sub[0]), mask=N.M_ALL,
+                                 dct_mode=N.DCT_BLOCK8)
+        got_h = engine.complexity(sub[1:], prev0=sub[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        droi = dbig.roi(y0, y1, x0, x1)
+        got_d = engine.complexity(droi.slice(1, 4), prev0=droi.frame(0), mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        for got in (got_h, got_d):
+            assert got.tobytes() == want.tobytes(), (y0, y1, x0, x1)
+        g = co.bgr2gray(np.ascontiguousarray(sub[1]))
+        assert (want[0]["hist_gray"] == co.hist_u8(g)).all()
+        assert int(want[0]["edge_count"]) == co.canny(g, 100, 200)[0]
+        # resized path reads the padded source rows too
+        want = engine.complexity(np.ascontiguousarray(sub[1:]), mask=N.M_GRAY_HIST | N.M_COLOR_HIST | N.M_DCT, resize=(40, 24))
+        got_d = engine.complexity(droi.slice(1, 4), mask=N.M_GRAY_HIST | N.M_COLOR_HIST | N.M_DCT, resize=(40, 24))
+        got_h = engine.complexity(sub[1:], mask=N.M_GRAY_HIST | N.M_COLOR_HIST | N.M_DCT, resize=(40, 24))
+        assert got_d.tobytes() == want.tobytes() and got_h.tobytes() == want.tobytes()
+
+
 def test_argument_errors(engine):
     from rtvqa_amd import _native as N
     fr = np.zeros((1, 32, 32, 3), np.uint8)
