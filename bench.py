@@ -139,10 +139,23 @@ def main():
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
     if dist_on:
         import torch.distributed as td
+        import datetime
+        tmo = datetime.timedelta(seconds=300)
         if args.backend == "nccl":
-            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+            try:  # device_id makes the RCCL communicator come up here, so a broken fabric shows now, on every rank
+                td.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo,
+                                      device_id=torch.device("cuda", device))
+                probe = torch.ones(1, device="cuda")
+                td.all_reduce(probe)
+                assert int(probe.item()) == world
+            except Exception as e:  # the two scalar reductions of this path do not need xGMI: finish over gloo
+                sys.stderr.write("[bench] rank %d: RCCL unavailable (%s); using gloo for the scalar reductions\n" % (rank, e))
+                if td.is_initialized():
+                    td.destroy_process_group()
+                args.backend, red_dev = "gloo", "cpu"
+                td.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            td.init_process_group("gloo", rank=rank, world_size=world)
+            td.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
 
     import rtvqa_amd
     from rtvqa_amd import _native as N
@@ -289,7 +302,7 @@ def main():
             "data": "synthetic (synth.s_%s v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
                     % (args.content, synth.GENERATOR_VERSION),
             "config": {"workload": wl["name"] if args.ssim_mode == "gauss" else
-                       wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"), "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams,
+                       wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"), "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams, "collective": (("rccl" if args.backend == "nccl" else "gloo") + " scalar all-reduce") if world > 1 else "none",
                        "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode, "parallelism": "1 stream/GPU x%d" % world},
             "roofline": roof, "kernels": kernels,
         }
