@@ -37,7 +37,7 @@ WORKLOADS = {
     "c2": dict(h=1080, w=1920, batch=256, full=False,
                name="1920x1080 frame_interval=1 PSNR+SSIM(gauss 11x11)+8x8 DCT(energy+temporal), BGR24 pairs"),
     "c3": dict(h=1080, w=1920, batch=256, full=True,
-               name="1920x1080 full suite (motion-SAD, DCT, temporal-DCT, Canny, gray+colour hist) + PSNR/SSIM"),
+               name="1920x1080 full suite (motion-SAD, DCT, temporal-DCT, Canny, ORB count, gray+colour hist) + PSNR/SSIM"),
     "c4": dict(h=2160, w=3840, batch=64, full=True, name="3840x2160 full suite + PSNR/SSIM"),
 }
 
@@ -62,6 +62,7 @@ def _cpu_item(item):
         out += list(co.block_sad(gp, g, 7)[:2])
         out.append(int(co.hist_u8(g).sum()))
         out += [int(co.hist_u8(dist, offset=c, step=3).sum()) for c in range(3)]
+        out.append(pl.process_orb_frame_for_parallel(dist))
     return out
 
 

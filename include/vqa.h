@@ -39,7 +39,7 @@ extern "C" {
 #define VQA_API
 #endif
 
-#define VQA_ABI_VERSION 1
+#define VQA_ABI_VERSION 2
 
 typedef enum vqa_status {
     VQA_OK = 0,
@@ -67,7 +67,9 @@ typedef enum vqa_mem_kind {
 #define VQA_M_EDGE          (1u << 4) /* process_edge_frame             complexity_metrics.py:477-504 */
 #define VQA_M_MOTION        (1u << 5) /* process_frame_complexity       complexity_metrics.py:313-343
                                          (block-SAD substitute for Farneback)         */
-#define VQA_M_ALL           0x3Fu
+#define VQA_M_ORB           (1u << 6) /* process_orb_frame_for_parallel complexity_metrics.py:367-389
+                                         (always on the 64x64 thumbnail, as the reference hard-codes) */
+#define VQA_M_ALL           0x7Fu
 
 /* dct_mode */
 #define VQA_DCT_AUTO   0 /* FULL when resize_w*resize_h <= 128*128, else BLOCK8            */
@@ -103,6 +105,8 @@ typedef struct vqa_frame_metrics {
     uint32_t edge_weak;          /* NMS survivors in (low, high]                            */
     uint32_t has_prev;           /* 1 if a previous frame was available                     */
     uint32_t hyst_steps;         /* diagnostics: relaxation steps summed over this frame's tiles       */
+    uint32_t orb_keypoints;      /* len(ORB_create().detectAndCompute(gray64)[0])  (:385-389)  */
+    uint32_t orb_response;       /* FAST score of that keypoint, 0 when there is none       */
 } vqa_frame_metrics;
 
 /* One 8-bit plane inside a frame buffer (planar YUV plane, or one channel of
@@ -175,7 +179,8 @@ enum vqa_kernel_id {
     VQA_K_SAD = 6,
     VQA_K_SSIM_GAUSS = 7,
     VQA_K_SSIM_FFMPEG = 8,
-    VQA_K_COUNT = 9
+    VQA_K_ORB = 9,       /* FAST-9/16 + NMS on the 64x64 thumbnail's centre */
+    VQA_K_COUNT = 10
 };
 /* When enabled, every kernel launch made by a submit call is bracketed by a
  * hipEvent pair recorded on the ctx stream; the elapsed times are accumulated

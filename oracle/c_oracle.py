@@ -59,6 +59,10 @@ def lib():
         L.vqo_ssim_ffmpeg.restype = C.c_double
         L.vqo_gauss11.argtypes = [C.POINTER(C.c_double)]
         L.vqo_gauss11.restype = None
+        L.vqo_fast9.argtypes = [u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, C.POINTER(C.c_int32), u8p]
+        L.vqo_fast9.restype = C.c_long
+        L.vqo_orb64_count.argtypes = [u8p, C.c_ssize_t, C.POINTER(C.c_int)]
+        L.vqo_orb64_count.restype = C.c_int
         _lib = L
     return _lib
 
@@ -191,3 +195,27 @@ def gauss11():
     g = (C.c_double * 11)()
     lib().vqo_gauss11(g)
     return np.array(g[:], np.float64)
+
+
+def fast9(gray, threshold=20, nonmax=True):
+    """cv2.FastFeatureDetector_create(threshold, nonmax).detect -> (n keypoints, score map, kept map)."""
+    gray = _c(gray)
+    h, w = gray.shape
+    sc = np.zeros((h, w), np.int32)
+    keep = np.zeros((h, w), np.uint8)
+    n = lib().vqo_fast9(_u8(gray), h, w, w, int(threshold), int(bool(nonmax)),
+                        sc.ctypes.data_as(C.POINTER(C.c_int32)), _u8(keep))
+    if n < 0:
+        raise MemoryError
+    return n, sc, keep
+
+
+def orb64_count(gray64):
+    """len(cv2.ORB_create().detectAndCompute(gray64, None)[0]) on a 64x64 image -> (count, FAST response)."""
+    gray64 = _c(gray64)
+    assert gray64.shape == (64, 64)
+    r = C.c_int(0)
+    n = lib().vqo_orb64_count(_u8(gray64), 64, C.byref(r))
+    if n < 0:
+        raise MemoryError
+    return n, r.value

@@ -240,3 +240,46 @@ def ewm_mean(x, alpha=0.8):
         den = den * (1 - alpha) + 1.0
         out[i] = num / den
     return out
+
+
+# FAST-9/16 in closed form (features2d/fast.cpp): score = max over the 16 runs of 9 contiguous circle
+# pixels of min(v - ring) or min(ring - v), minus 1; corner iff that maximum exceeds the threshold.
+_FAST_DX = (0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1)
+_FAST_DY = (3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3)
+
+
+def fast9_scores(gray, threshold=20):
+    """score map (0 = not a corner) of every pixel at least 3 pixels inside the image."""
+    g = np.asarray(gray, np.int32)
+    h, w = g.shape
+    sc = np.zeros((h, w), np.int32)
+    if h < 7 or w < 7:
+        return sc
+    v = g[3:h - 3, 3:w - 3]
+    ring = np.stack([g[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in zip(_FAST_DX, _FAST_DY)])
+    d = v[None] - ring
+    best = np.full(v.shape, -256, np.int32)
+    for s0 in range(16):
+        idx = [(s0 + j) % 16 for j in range(9)]
+        best = np.maximum(best, np.maximum(d[idx].min(0), (-d[idx]).min(0)))
+    sc[3:h - 3, 3:w - 3] = np.where(best > threshold, best - 1, 0)
+    return sc
+
+
+def fast9_nms(scores):
+    """strict 3x3 non-max suppression of a FAST score map -> boolean keep map."""
+    s = np.asarray(scores, np.int32)
+    p = np.pad(s, 1)
+    keep = s > 0
+    h, w = s.shape
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            if dx or dy:
+                keep &= s > p[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+    return keep
+
+
+def orb64_count(gray64, threshold=20):
+    """ORB keypoint count of a 64x64 image (see oracle/vqa_oracle.c vqo_orb64_count)."""
+    keep = fast9_nms(fast9_scores(gray64, threshold))
+    return int(keep[31:33, 31:33].sum())

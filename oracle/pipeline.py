@@ -46,6 +46,12 @@ def process_edge_frame(frame, resize_width, resize_height):
     return np.int64(co.canny(gray_frame, 100, 200)[0])
 
 
+# complexity_metrics.py:367-389
+def process_orb_frame_for_parallel(frame):
+    gray_frame = co.bgr2gray(co.resize_linear(frame, 64, 64))
+    return co.orb64_count(gray_frame)[0]
+
+
 # complexity_metrics.py:313-343 — block-SAD substitute (spec: vqa_oracle.c vqo_block_sad)
 def process_frame_complexity(frame_pair, sad_range=7):
     frame, prev_frame = frame_pair
@@ -100,7 +106,7 @@ def calculate_temporal_dct(frames, resize_width, resize_height, frame_interval=1
     return (np.mean(sm) if len(sm) > 0 else 0.0), energies
 
 
-# complexity_metrics.py:246-310 (ORB slot: NaN — out of scope; fps from constant-rate timestamps)
+# complexity_metrics.py:246-310 (fps from constant-rate timestamps)
 def calculate_average_scene_complexity(frames, resize_width, resize_height, frame_interval=10, smoothing_factor=0.8,
                                        num_workers=None, batch_size=100, dct_mode="full", fps=30.0,
                                        dispatcher=serial_map, return_series=False):
@@ -114,6 +120,7 @@ def calculate_average_scene_complexity(frames, resize_width, resize_height, fram
     dct = dispatcher(sel, functools.partial(process_dct_frame, dct_mode=dct_mode, **kw), num_workers, batch_size)
     hist = dispatcher(sel, functools.partial(process_histogram_frame, **kw), num_workers, batch_size)
     edge = dispatcher(sel, functools.partial(process_edge_frame, **kw), num_workers, batch_size)
+    orb = dispatcher(sel, process_orb_frame_for_parallel, num_workers, batch_size)
     color = dispatcher(sel, functools.partial(process_color_histogram_frame, **kw), num_workers, batch_size)
     temporal, temporal_series = calculate_temporal_dct(frames, resize_width, resize_height, frame_interval,
                                                        smoothing_factor, dct_mode)
@@ -126,10 +133,10 @@ def calculate_average_scene_complexity(frames, resize_width, resize_height, fram
             warnings.simplefilter("ignore")
             return np.mean(no.ewm_mean(x, smoothing_factor))
 
-    out = (pooled(motion), pooled(dct), pooled(hist), pooled(edge), float("nan"), pooled(color), temporal,
+    out = (pooled(motion), pooled(dct), pooled(hist), pooled(edge), pooled(orb), pooled(color), temporal,
            pooled(fpsv))
     if return_series:
-        return out, dict(motion=motion, dct=dct, hist=hist, edge=edge, color=color, temporal=temporal_series)
+        return out, dict(motion=motion, dct=dct, hist=hist, edge=edge, orb=orb, color=color, temporal=temporal_series)
     return out
 
 

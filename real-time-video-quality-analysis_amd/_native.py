@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvqa_hip.so")
 
-VQA_ABI_VERSION = 1
+VQA_ABI_VERSION = 2
 
 VQA_OK = 0
 VQA_ERR_INVALID = -1
@@ -28,7 +28,8 @@ M_DCT = 1 << 2
 M_TEMPORAL_DCT = 1 << 3
 M_EDGE = 1 << 4
 M_MOTION = 1 << 5
-M_ALL = 0x3F
+M_ORB = 1 << 6
+M_ALL = 0x7F
 
 (K_GRAY_HIST, K_RESIZE, K_DCT8, K_DCT_FULL, K_CANNY_NMS, K_CANNY_HYST, K_SAD, K_SSIM_GAUSS, K_SSIM_FFMPEG,
  K_COUNT) = range(10)
@@ -57,7 +58,7 @@ class VqaFrameMetrics(C.Structure):
                 ("edge_strong", C.c_uint32),
                 ("edge_weak", C.c_uint32),
                 ("has_prev", C.c_uint32),
-                ("hyst_steps", C.c_uint32)]
+                ("hyst_steps", C.c_uint32), ("orb_keypoints", C.c_uint32), ("orb_response", C.c_uint32)]
 
 
 class VqaPlaneDesc(C.Structure):

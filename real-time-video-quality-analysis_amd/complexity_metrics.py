@@ -164,11 +164,13 @@ def _scalar(kind, rec):
         return np.int64(rec["edge_count"])
     if kind == "motion":
         return _motion_magnitude(rec)
+    if kind == "orb":
+        return int(rec["orb_keypoints"])
     raise KeyError(kind)
 
 
 _MASK = {"dct": N.M_DCT, "temporal": N.M_TEMPORAL_DCT, "hist": N.M_GRAY_HIST, "color": N.M_COLOR_HIST,
-         "edge": N.M_EDGE, "motion": N.M_MOTION}
+         "edge": N.M_EDGE, "motion": N.M_MOTION, "orb": N.M_ORB}
 
 
 # ---------------------------------------------------------------------------
@@ -223,12 +225,17 @@ def process_temporal_dct_frame(prev_gray_frame, curr_gray_frame, resize_width, r
 
 
 def process_orb_frame_for_parallel(frame):
-    """complexity_metrics.py:367-389 — OUT OF SCOPE (not named by north_star)."""
-    raise NotImplementedError("ORB keypoint counting is outside this build's hot-path scope")
+    """complexity_metrics.py:367-389 — number of ORB keypoints of the 64x64 thumbnail (the reference
+    hard-codes the size and every ORB parameter at its default)."""
+    frame = np.asarray(frame)
+    if frame.ndim == 2:
+        frame = np.repeat(frame[..., None], 3, axis=2)
+    rec = get_engine().complexity(frame[None], mask=N.M_ORB)
+    return _scalar("orb", rec[0])
 
 
 _KNOWN = {process_dct_frame: "dct", process_histogram_frame: "hist", process_color_histogram_frame: "color",
-          process_edge_frame: "edge", process_frame_complexity: "motion"}
+          process_edge_frame: "edge", process_frame_complexity: "motion", process_orb_frame_for_parallel: "orb"}
 
 
 def _unwrap(func, kwargs):
@@ -264,7 +271,7 @@ def process_in_batches(frames, process_func, num_workers, batch_size=100, **kwar
         if kind == "motion":
             results.extend(_motion_batch(eng, batch))
             continue
-        resize = (kw["resize_width"], kw["resize_height"])
+        resize = None if kind == "orb" else (kw["resize_width"], kw["resize_height"])
         arr = np.stack([np.asarray(f) for f in batch])
         rec = eng.complexity(arr, mask=_MASK[kind], resize=resize)
         results.extend(_scalar(kind, r) for r in rec)
@@ -303,12 +310,12 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
     """Per-frame series for the frames the reference measures, from ONE fused pass.
 
     Returns dict kind -> list, each in the reference's sample order:
-      motion/dct/hist/edge/color : T-1 samples (selected frames S_1..S_{T-1}; :268-290)
+      motion/dct/hist/edge/orb/color : T-1 samples (selected frames S_1..S_{T-1}; :268-290)
       temporal                   : T-2 samples (S_1->S_2 ... ; :533-537)
     """
     fr = _open_frames(video)
     idx = selected_indices(_num_frames(fr), frame_interval)
-    out = {k: [] for k in ("motion", "dct", "hist", "edge", "color", "temporal")}
+    out = {k: [] for k in ("motion", "dct", "hist", "edge", "orb", "color", "temporal")}
     if len(idx) < 2:  # unopenable / too short: empty series, as the reference's empty pair list (:95-97)
         return out
     eng = engine or get_engine()
@@ -328,7 +335,7 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
             prev0 = np.asarray(fr[prev_i])
         rec = eng.complexity(batch, prev0=prev0, mask=mask, params=params)
         for j, r in enumerate(rec):
-            for kind in ("motion", "dct", "hist", "edge", "color"):
+            for kind in ("motion", "dct", "hist", "edge", "orb", "color"):
                 if mask & _MASK[kind]:
                     out[kind].append(_scalar(kind, r))
             # the reference's first pair only primes prev_gray_frame (:533-537)
@@ -349,7 +356,7 @@ def calculate_average_scene_complexity(video_path, resize_width, resize_height, 
                                        smoothing_factor=0.8, num_workers=None, batch_size=100, fps=30.0):
     """complexity_metrics.py:246-310.  Returns the 8-tuple in the reference's order (:301-310):
     (motion, dct, histogram, edge, orb, colour_histogram, temporal_dct, framerate_variation).
-    `video_path` may be a .npy path, an ndarray [N,H,W,3] or DeviceFrames.  orb is NaN (out of scope)."""
+    `video_path` may be a .npy path, an ndarray [N,H,W,3] or DeviceFrames."""
     s = complexity_series(video_path, resize_width, resize_height, frame_interval, batch_size)
 
     def pooled(x):
@@ -361,7 +368,7 @@ def calculate_average_scene_complexity(video_path, resize_width, resize_height, 
     frame_timestamps = extract_frame_timestamps(video_path, frame_interval, fps)
     timestamp_pairs = list(zip(frame_timestamps[:-1], frame_timestamps[1:]))
     framerate_variation = process_in_batches(timestamp_pairs, process_frame_interval_for_parallel, num_workers, batch_size)
-    return (pooled(s["motion"]), pooled(s["dct"]), pooled(s["hist"]), pooled(s["edge"]), float("nan"),
+    return (pooled(s["motion"]), pooled(s["dct"]), pooled(s["hist"]), pooled(s["edge"]), pooled(s["orb"]),
             pooled(s["color"]), temporal_dct_complexity, pooled(framerate_variation))
 
 

@@ -359,6 +359,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     const int pp = align_up(pw, 64), gp = align_up(w, 64);
     const bool want_gh = mask & VQA_M_GRAY_HIST, want_ch = mask & VQA_M_COLOR_HIST, want_dct = mask & VQA_M_DCT;
     const bool want_t = mask & VQA_M_TEMPORAL_DCT, want_e = mask & VQA_M_EDGE, want_m = mask & VQA_M_MOTION;
+    const bool want_orb = mask & VQA_M_ORB;
     const bool has_prev0 = prev0 != nullptr;
 
     // ---- bring frames to the device if they are on the host
@@ -406,8 +407,9 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     vqa_frame_metrics *res = (vqa_frame_metrics *)c->res_dev.p;
 
     // ---- planes
-    const bool need_full = !resized || want_m;
-    const bool need_planes = resized && (want_gh || want_ch || want_dct || want_t || want_e);
+    const bool want_plane = want_gh || want_ch || want_dct || want_t || want_e; // kernels that read the configured plane
+    const bool need_full = (!resized && want_plane) || want_m;
+    const bool need_planes = resized && want_plane;
     const int64_t full_stride = (int64_t)h * gp, plane_stride = (int64_t)ph * pp;
     uint8_t *gfull = nullptr, *pA = nullptr, *pB = nullptr;
     if (need_full) {
@@ -529,6 +531,15 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         }
         launch_canny_finish(st, n, res);
         c->last_has_state = true;
+    }
+
+    // ---- ORB keypoint count: always on the 64x64 thumbnail (:385-386), straight from the BGR frames
+    if (want_orb) {
+        resize_tabs T64;
+        rc = get_tabs(c, h, w, 64, 64, T64);
+        if (rc) return rc;
+        prof_scope ps_(c, VQA_K_ORB);
+        launch_orb64(st, dframes, n, h, w, frame_stride, row_stride, T64.xofs, T64.xa, T64.yofs, T64.yb, T64.mode, res);
     }
 
     HIPCHK(c, hipGetLastError());
@@ -663,7 +674,7 @@ const char *vqa_kernel_name(int id)
 {
     static const char *names[VQA_K_COUNT] = {"k_bgr2gray_hist", "k_resize_planes", "k_dct8", "k_dct_full(gemm_nt x4)",
                                              "k_canny_nms", "k_canny_hyst", "k_block_sad", "k_ssim_gauss",
-                                             "k_ssim_ffmpeg"};
+                                             "k_ssim_ffmpeg", "k_orb64"};
     return (id >= 0 && id < VQA_K_COUNT) ? names[id] : "?";
 }
 

@@ -16,6 +16,11 @@ void launch_resize_planes(hipStream_t st, const uint8_t *bgr, int n, int h, int 
                           const int32_t *yofs, const int32_t *yb, int mode, uint8_t *planeA, uint8_t *planeB, int pp,
                           int64_t plane_stride, vqa_frame_metrics *res, bool gray_hist, bool color_hist, bool sum2);
 
+// k_orb.hip
+void launch_orb64(hipStream_t st, const uint8_t *bgr, int n, int h, int w, int64_t frame_stride, int64_t row_stride,
+                  const int32_t *xofs, const int32_t *xa, const int32_t *yofs, const int32_t *yb, int mode,
+                  vqa_frame_metrics *res);
+
 // k_dct8.hip
 int dct8_blocks_per_frame(int h, int w);
 void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,

@@ -133,6 +133,33 @@ VQA_HD int canny_classify(int m, int gx, int gy, const int nb[8], int low, int h
     return m > high ? 2 : 1;
 }
 
+// FAST-9/16 corner score of one pixel (OpenCV 4.x fast.cpp / fast_score.cpp cornerScore<16>, as used by
+// cv2.ORB_create().detectAndCompute, complexity_metrics.py:385-387).
+//   v      : the centre pixel;  ring[k]: the 16 pixels of the radius-3 Bresenham circle in circular order
+//   thr    : the FAST threshold (ORB's default fastThreshold = 20)
+// The pixel is a corner iff some run of 9 contiguous ring pixels is entirely darker than v - thr or
+// entirely brighter than v + thr (strict).  With A = max over the 16 runs of min(v - ring) and
+// B = max over the runs of min(ring - v), that is max(A, B) > thr, and the score OpenCV attaches to the
+// corner (the largest threshold at which it would still be one) is max(A, B) - 1.
+// returns the score for a corner, 0 otherwise (a corner's score is >= thr >= 1 whenever thr >= 1)
+VQA_HD int fast9_score(int v, const int ring[16], int thr)
+{
+    int best = -256;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        int lo = 255, hi = 255; // min(v - ring), min(ring - v) over the run s .. s+8
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            const int d = v - ring[(s + j) & 15];
+            lo = d < lo ? d : lo;
+            hi = -d < hi ? -d : hi;
+        }
+        const int m = lo > hi ? lo : hi;
+        best = m > best ? m : best;
+    }
+    return best > thr ? best - 1 : 0;
+}
+
 // SSIM index from the four window moments used by the Gaussian kernel:
 //   mx, my = E[x], E[y];  sq = E[x^2 + y^2];  xy = E[x y]
 VQA_HD float ssim_from_moments(float mx, float my, float sq, float xy)

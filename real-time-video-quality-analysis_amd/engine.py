@@ -24,7 +24,7 @@ FRAME_DTYPE = np.dtype([
     ("edge_strong", np.uint32),
     ("edge_weak", np.uint32),
     ("has_prev", np.uint32),
-    ("hyst_steps", np.uint32),
+    ("hyst_steps", np.uint32), ("orb_keypoints", np.uint32), ("orb_response", np.uint32),
 ], align=True)
 PLANE_DTYPE = np.dtype([("sse", np.uint64), ("ssim", np.float64)], align=True)
 assert FRAME_DTYPE.itemsize == C.sizeof(N.VqaFrameMetrics), (FRAME_DTYPE.itemsize, C.sizeof(N.VqaFrameMetrics))

@@ -16,6 +16,7 @@ int shim_canny_classify(int m, int gx, int gy, const int *nb, int low, int high)
 {
     return vqa::canny_classify(m, gx, gy, nb, low, high);
 }
+int shim_fast9_score(int v, const int *ring, int thr) { return vqa::fast9_score(v, ring, thr); }
 float shim_ssim_moments(float mx, float my, float sq, float xy) { return vqa::ssim_from_moments(mx, my, sq, xy); }
 float shim_ssim_ffmpeg_end1(int s1, int s2, int ss, int s12) { return vqa::ssim_ffmpeg_end1(s1, s2, ss, s12); }
 }

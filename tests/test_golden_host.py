@@ -92,7 +92,8 @@ def test_bad_sources_raise_like_reference():
         cm.validate_video_path(123)
     with pytest.raises(ValueError):
         cm.validate_video_path("clip.txt")
-    with pytest.raises(NotImplementedError):
+    from rtvqa_amd import _native as N
+    with pytest.raises(N.VqaError):  # no CPU fallback: a kernel call without a device fails loudly
         cm.process_orb_frame_for_parallel(np.zeros((8, 8, 3), np.uint8))
 
 

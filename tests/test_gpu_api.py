@@ -33,6 +33,10 @@ def test_per_frame_callables_match_reference_shaped_oracle():
     assert isinstance(cm.process_edge_frame(f, 64, 64), np.int64)
     assert cm.process_frame_complexity((f, p)) == pl.process_frame_complexity((f, p))
     assert cm.process_frame_complexity((f, None)) == 0.0
+    assert cm.process_orb_frame_for_parallel(f) == pl.process_orb_frame_for_parallel(f)
+    spot = np.full((96, 128, 3), 50, np.uint8)
+    spot[48:50, 64:66] = 250
+    assert cm.process_orb_frame_for_parallel(spot) == pl.process_orb_frame_for_parallel(spot) == 1
     from oracle import c_oracle as co
     pg, cg = co.resize_linear(co.bgr2gray(p), 64, 64), co.resize_linear(co.bgr2gray(f), 64, 64)
     assert _close(cm.process_temporal_dct_frame(pg, cg, 64, 64), pl.process_temporal_dct_frame(pg, cg, 64, 64, "full"))
@@ -50,6 +54,8 @@ def test_process_in_batches_known_kernels_and_order():
     pairs = [(fr[i], fr[i - 1]) for i in range(1, 7)]
     got = cm.process_in_batches(pairs, cm.process_frame_complexity, 2, batch_size=4)
     assert got == [pl.process_frame_complexity(pr) for pr in pairs]
+    assert cm.process_in_batches(fr, cm.process_orb_frame_for_parallel, 4, batch_size=3) == \
+        [pl.process_orb_frame_for_parallel(f) for f in fr]
     unchained = [(fr[0], fr[3]), (fr[5], None), (fr[2], fr[6])]
     got = cm.process_in_batches(unchained, cm.process_frame_complexity, 2)
     assert got == [pl.process_frame_complexity(pr) for pr in unchained]

@@ -458,6 +458,38 @@ def test_random_geometries_sad_and_resize(engine, seed):
         assert _rel(rec[i]["dct_energy"], e) < RTOL and (l1 == 0 or _rel(rec[i]["temporal_dct_l1"], l1) < RTOL)
 
 
+def _orb_oracle(frame):
+    return co.orb64_count(co.bgr2gray(co.resize_linear(frame, 64, 64)))
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (128, 128), (270, 480), (97, 131), (40, 52), (1080, 1920)])
+def test_orb_keypoint_count(engine, h, w):
+    """process_orb_frame_for_parallel (:367-389): FAST-9/16 + NMS at the centre of the 64x64 thumbnail."""
+    from rtvqa_amd import _native as N
+    rng = _rng(h + w)
+    n = 48 if h < 1000 else 6
+    fr = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8) if h < 1000 else _frames("natural", n, h, w, seed=3)
+    # plant isolated bright / dark spots over a flat centre in some frames so that keypoints do occur
+    cy, cx = h // 2, w // 2
+    ry, rx = max(4 * h // 64, 4), max(4 * w // 64, 4)
+    for i in range(0, n, 3):
+        fr[i, cy - ry:cy + ry, cx - rx:cx + rx] = 60 if i % 2 else 200
+        oy, ox = int(rng.integers(-h // 64 - 1, h // 64 + 2)), int(rng.integers(-w // 64 - 1, w // 64 + 2))
+        sy, sx = max(h // 64, 1), max(w // 64, 1)
+        fr[i, cy + oy - sy:cy + oy + sy, cx + ox - sx:cx + ox + sx] = 255 if i % 2 else 0
+    rec = engine.complexity(fr, mask=N.M_ORB)
+    want = [_orb_oracle(f) for f in fr]
+    got = [(int(r["orb_keypoints"]), int(r["orb_response"])) for r in rec]
+    assert got == want
+    assert {c for c, _ in want} == {0, 1} or h >= 1000, "test frames should exercise both outcomes"
+    # the metric ignores the configured resize and rides along with the rest of the suite unchanged
+    rec2 = engine.complexity(fr[:4], mask=N.M_ALL, resize=(48, 32))
+    assert [(int(r["orb_keypoints"]), int(r["orb_response"])) for r in rec2] == want[:4]
+    dev = engine.upload(fr[:4])
+    rec3 = engine.complexity(dev, mask=N.M_ORB | N.M_GRAY_HIST)
+    assert [(int(r["orb_keypoints"]), int(r["orb_response"])) for r in rec3] == want[:4]
+
+
 def test_region_of_interest_padded_rows(engine):
     """row_stride > 3w: a window inside larger frames, host and device resident, odd (unaligned) origins.
     The host window ends at the very last byte of its parent array, so any read past a row's 3w bytes

@@ -24,6 +24,7 @@ def shim(tmp_path_factory):
     L.shim_ssim_moments.restype = C.c_float
     L.shim_ssim_moments.argtypes = [C.c_float] * 4
     L.shim_ssim_ffmpeg_end1.restype = C.c_float
+    L.shim_fast9_score.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
     return L
 
 
@@ -96,3 +97,26 @@ def test_ssim_formulas(shim):
         ref = (np.float32(2 * s1 * s2 + c1) * np.float32(2 * (s12 * 64 - s1 * s2) + c2)) / (
             np.float32(s1 * s1 + s2 * s2 + c1) * np.float32(ss * 64 - s1 * s1 - s2 * s2 + c2))
         assert abs(v - float(ref)) <= 2e-7 * abs(float(ref))
+
+
+def test_fast9_score_matches_oracle(shim):
+    """The device's closed-form FAST-9/16 score against the oracle's procedural OpenCV restatement."""
+    dx = (0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1)
+    dy = (3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3)
+    rng = np.random.default_rng(5)
+    import scipy.ndimage as ndi
+    imgs = [rng.integers(0, 256, (40, 40), dtype=np.uint8),
+            ndi.uniform_filter(rng.integers(0, 256, (40, 40)).astype(float), 3).astype(np.uint8)]
+    sq = np.full((40, 40), 30, np.uint8)
+    sq[10:25, 12:30] = 200
+    imgs.append(sq)
+    corners = 0
+    for g in imgs:
+        for thr in (20, 7):
+            _, sc, _ = co.fast9(g, thr, True)
+            for y in range(3, 37):
+                for x in range(3, 37):
+                    ring = (C.c_int * 16)(*[int(g[y + dy[k], x + dx[k]]) for k in range(16)])
+                    assert shim.shim_fast9_score(int(g[y, x]), ring, thr) == sc[y, x], (y, x, thr)
+            corners += int((sc > 0).sum())
+    assert corners > 50

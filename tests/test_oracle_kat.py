@@ -208,8 +208,82 @@ def test_pipeline_sample_counts_and_order():
     out, series = pl.calculate_average_scene_complexity(frames, 32, 32, frame_interval=10, return_series=True)
     # 45 frames, interval 10 -> selected 9,19,29,39 -> T=4: 3 per-frame samples, 2 temporal samples
     assert len(series["dct"]) == 3 and len(series["motion"]) == 3 and len(series["temporal"]) == 2
-    assert len(out) == 8 and np.isnan(out[4])
+    assert len(out) == 8 and len(series["orb"]) == 3 and 0.0 <= out[4] <= 1.0
     assert abs(out[7] - 3.0) < 1e-9  # 30 fps / interval 10
     # too short a clip: empty series -> NaN means, temporal 0.0 (:541)
     out0 = pl.calculate_average_scene_complexity(frames[:15], 32, 32, frame_interval=10)
     assert np.isnan(out0[1]) and out0[6] == 0.0
+
+
+# ---- FAST-9/16 + ORB count on the 64x64 thumbnail ------------------------------------
+def _orb_frame(kind, v_bg=40, v_fg=220):
+    g = np.full((64, 64), v_bg, np.uint8)
+    if kind == "quadrant":      # the corner of a bright quadrant sits exactly on pixel (32, 32)
+        g[32:, 32:] = v_fg
+    elif kind == "dot":         # an isolated bright pixel inside the kept 2x2 window
+        g[32, 31] = v_fg
+    elif kind == "twodots":     # two adjacent corners in the window: NMS keeps the stronger one only
+        g[31, 31] = v_fg
+        g[31, 32] = v_fg - 20
+    elif kind == "wedge":       # a dark wedge whose tip is at (31, 32)
+        g[:] = v_fg
+        for y in range(32, 64):
+            g[y, 31 - (y - 32) // 2:31 + (y - 32) // 2 + 1] = v_bg
+    elif kind == "offcentre":   # an isolated bright pixel just outside the kept 2x2 window
+        g[33, 32] = v_fg
+    elif kind == "edge":        # a straight edge through the centre: no run of 9
+        g[:, 32:] = v_fg
+    return g
+
+
+def test_fast9_known_answers():
+    flat = np.full((30, 30), 77, np.uint8)
+    assert co.fast9(flat)[0] == 0
+    # one bright pixel: all 16 circle pixels are darker by 100 -> score 99, the only keypoint
+    dot = flat.copy()
+    dot[15, 15] = 177
+    n, sc, keep = co.fast9(dot, 20, True)
+    assert n == 1 and sc[15, 15] == 99 and keep[15, 15] == 1 and (sc > 0).sum() == 1
+    assert co.fast9(dot, 100, True)[0] == 0 and co.fast9(dot, 99, True)[0] == 1  # strict: corner iff diff > t
+    # a straight step edge never has 9 contiguous circle pixels on one side beyond the threshold ... at the
+    # edge pixel itself exactly 7 of 16 lie strictly across the edge
+    assert co.fast9(_orb_frame("edge"))[0] == 0
+    # nothing within 3 pixels of the border is ever tested
+    b = flat.copy()
+    b[2, 10] = 255
+    assert co.fast9(b)[0] == 0
+    # closed form (np_oracle) == procedural form (c_oracle) on noise, all thresholds
+    g = _rng(41).integers(0, 256, (50, 70), dtype=np.uint8)
+    for thr in (1, 20, 60, 254):
+        n, sc, keep = co.fast9(g, thr, True)
+        s2 = no.fast9_scores(g, thr)
+        assert (sc == s2).all() and (keep.astype(bool) == no.fast9_nms(s2)).all() and n == int(keep.sum())
+    # mirror/transpose symmetry of detection + strict NMS
+    n0, sc0, k0 = co.fast9(g, 20, True)
+    for f in (np.fliplr, np.flipud, np.transpose):
+        n1, sc1, k1 = co.fast9(np.ascontiguousarray(f(g)), 20, True)
+        assert n1 == n0 and (f(sc0) == sc1).all() and (f(k0) == k1).all()
+
+
+def test_orb64_count_window_and_nms():
+    assert co.orb64_count(np.full((64, 64), 9, np.uint8)) == (0, 0)
+    assert co.orb64_count(_orb_frame("dot")) == (1, 179)  # 220 - 40 - 1
+    assert co.orb64_count(_orb_frame("twodots")) == (1, 179) and no.orb64_count(_orb_frame("twodots")) == 1
+    assert co.fast9(_orb_frame("twodots"), 20, False)[0] == 2
+    # a binary quadrant corner: (32,32) and (33,33) are both corners with EQUAL scores, and strict NMS drops ties
+    q = _orb_frame("quadrant")
+    _, sc, keep = co.fast9(q)
+    assert sc[32, 32] == sc[33, 33] == 179 and not keep[32, 32] and co.orb64_count(q) == (0, 0)
+    assert co.orb64_count(_orb_frame("wedge"))[0] == no.orb64_count(_orb_frame("wedge"))
+    assert co.orb64_count(_orb_frame("offcentre")) == (0, 0)   # a real FAST keypoint, outside 31 <= x,y < 33
+    assert co.fast9(_orb_frame("offcentre"))[0] == 1
+    assert co.orb64_count(_orb_frame("edge")) == (0, 0)
+    # the four window pixels are mutual neighbours and NMS is strict: never more than one keypoint
+    rng = _rng(42)
+    seen = set()
+    for _ in range(300):
+        g = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+        n, r = co.orb64_count(g)
+        assert n == no.orb64_count(g) and n in (0, 1) and (r > 0) == (n == 1)
+        seen.add(n)
+    assert seen == {0, 1}
