@@ -34,22 +34,38 @@ def submit(i):
     e.complexity_submit(d[1:], d[0], N.M_DCT | N.M_TEMPORAL_DCT, params)
 
 
+# "once": each buffer crosses PCIe ONCE per step (vqa_copy_h2d, async on the ctx stream) and both submits
+# read the device copy; "submit" hands the pinned host pointers to both submits (dist crosses twice)
+from rtvqa_amd.engine import DeviceBuffer, DeviceFrames
+dbufs = [(DeviceBuffer(e, fb * (B + 1)), DeviceBuffer(e, fb * (B + 1))) for e in engs]
+
+
+def submit_once(i):
+    e = engs[i & 1]; r, d = bufs[i & 1]; dr, dd = dbufs[i & 1]
+    N.check(e.lib.vqa_copy_h2d(e.ctx, dr.ptr, r.ctypes.data, r.nbytes), "h2d", e.ctx)
+    N.check(e.lib.vqa_copy_h2d(e.ctx, dd.ptr, d.ctypes.data, d.nbytes), "h2d", e.ctx)
+    fr, fd = DeviceFrames(dr.ptr, B + 1, h, w, owner=dr), DeviceFrames(dd.ptr, B + 1, h, w, owner=dd)
+    e.quality_submit(fr.slice(1, B + 1), fd.slice(1, B + 1), planes, N.SSIM_GAUSS)
+    e.complexity_submit(fd.slice(1, B + 1), fd.frame(0), N.M_DCT | N.M_TEMPORAL_DCT, params)
+
+
 def wait(i):
     e = engs[i & 1]
     return e.quality_wait(), e.complexity_wait()
 
 
-for mode in ("serial", "overlapped"):
-    submit(0); wait(0)
+for mode in ("serial", "overlapped", "overlapped-once"):
+    sub = submit_once if mode.endswith("once") else submit
+    sub(0); wait(0)
     t0 = time.perf_counter()
     if mode == "serial":
         for i in range(steps):
-            submit(0); wait(0)
+            sub(0); wait(0)
     else:
-        submit(0)
+        sub(0)
         for i in range(1, steps):
-            submit(i); wait(i - 1)
+            sub(i); wait(i - 1)
         wait(steps - 1)
     dt = time.perf_counter() - t0
-    gb = 2 * fb * (B + 1) * steps / 1e9
+    gb = (2 if mode.endswith("once") else 3) * fb * (B + 1) * steps / 1e9
     print("%s: %.0f frames/s PCIe-inclusive, %.1f GB/s H2D" % (mode, B * steps / dt, gb / dt))
