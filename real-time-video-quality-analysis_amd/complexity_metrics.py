@@ -17,7 +17,6 @@ Differences that are deliberate:
   * the dispatcher does not fork (a HIP context does not survive fork): a batch of
     frames is one kernel launch instead of one pickled frame per pool task;
   * motion is block-SAD, not Farneback (BASELINE.json north_star);
-  * ORB keypoint counting is out of scope: its tuple slot holds NaN.
 No metric is ever computed on the CPU here; without the HIP library this module
 raises on first use.
 """
@@ -29,6 +28,7 @@ import numpy as np
 
 from . import _native as N
 from .engine import DeviceFrames, Engine
+from .pooling import pooling_weights, shard_range
 from .pooling import smooth_data as _ewm
 
 logger = logging.getLogger(__name__)
@@ -306,22 +306,28 @@ def _motion_batch(eng, pairs):
 # the aggregator
 # ---------------------------------------------------------------------------
 def complexity_series(video, resize_width, resize_height, frame_interval=10, batch_size=100, engine=None,
-                      dct_mode=N.DCT_AUTO, mask=N.M_ALL):
+                      dct_mode=N.DCT_AUTO, mask=N.M_ALL, shard=None):
     """Per-frame series for the frames the reference measures, from ONE fused pass.
 
     Returns dict kind -> list, each in the reference's sample order:
       motion/dct/hist/edge/orb/color : T-1 samples (selected frames S_1..S_{T-1}; :268-290)
       temporal                   : T-2 samples (S_1->S_2 ... ; :533-537)
+    shard=(rank, world): only this rank's contiguous range of the T-1 samples is computed (the
+    shard also reads the ONE selected frame before its first, as the pair metrics' halo); the lists then hold
+    that range only and out["range"] = (lo, hi) gives its place in the whole series.
     """
     fr = _open_frames(video)
     idx = selected_indices(_num_frames(fr), frame_interval)
     out = {k: [] for k in ("motion", "dct", "hist", "edge", "orb", "color", "temporal")}
-    if len(idx) < 2:  # unopenable / too short: empty series, as the reference's empty pair list (:95-97)
+    lo, hi = shard_range(max(len(idx) - 1, 0), *shard) if shard is not None else (0, max(len(idx) - 1, 0))
+    out["range"] = (lo, hi)
+    if len(idx) < 2 or hi <= lo:  # unopenable / too short: empty series, as the reference's empty pair list (:95-97)
         return out
     eng = engine or get_engine()
     params = eng.make_params(resize=(resize_width, resize_height), dct_mode=dct_mode)
-    sel = idx[1:]
-    prev_i = idx[0]
+    sel = idx[1 + lo:1 + hi]
+    prev_i = idx[lo]
+    first_global = lo == 0
     for a in range(0, len(sel), batch_size):
         chunk = sel[a:a + batch_size]
         if isinstance(fr, DeviceFrames):
@@ -339,7 +345,7 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
                 if mask & _MASK[kind]:
                     out[kind].append(_scalar(kind, r))
             # the reference's first pair only primes prev_gray_frame (:533-537)
-            if (mask & N.M_TEMPORAL_DCT) and not (a == 0 and j == 0):
+            if (mask & N.M_TEMPORAL_DCT) and not (first_global and a == 0 and j == 0):
                 out["temporal"].append(_scalar("temporal", r))
         prev_i = chunk[-1]
     return out
@@ -370,6 +376,52 @@ def calculate_average_scene_complexity(video_path, resize_width, resize_height, 
     framerate_variation = process_in_batches(timestamp_pairs, process_frame_interval_for_parallel, num_workers, batch_size)
     return (pooled(s["motion"]), pooled(s["dct"]), pooled(s["hist"]), pooled(s["edge"]), pooled(s["orb"]),
             pooled(s["color"]), temporal_dct_complexity, pooled(framerate_variation))
+
+
+def calculate_average_scene_complexity_sharded(video_path, resize_width, resize_height, frame_interval=10,
+                                               smoothing_factor=0.8, batch_size=100, fps=30.0, group=None,
+                                               series_fn=None):
+    """calculate_average_scene_complexity of ONE long stream on N GPUs, one process per GPU.
+
+    Every rank measures a contiguous range of the selected frames (plus the one frame before it) on its own
+    device, no frame ever moves between GPUs.  mean(EWM(x)) is a fixed linear functional sum_i c_i x_i
+    (pooling.pooling_weights), so each rank forms its partial sums with GLOBAL sample indices and ONE float64
+    SUM all-reduce of 7 scalars (RCCL when the process group is "nccl") yields, on every rank, the 8-tuple the
+    single-process function returns (to ~1e-15 relative: the reduction order differs).
+    Requires an initialised torch.distributed process group; `video_path` as for the single-process call.
+    `series_fn` replaces complexity_series (tests inject a CPU stand-in; the product default is the HIP path)."""
+    import torch
+    import torch.distributed as td
+    rank, world = td.get_rank(group), td.get_world_size(group)
+    s = (series_fn or complexity_series)(video_path, resize_width, resize_height, frame_interval, batch_size,
+                                         shard=(rank, world))
+    lo, hi = s["range"]
+    T = len(selected_indices(_num_frames(_open_frames(video_path)), frame_interval)) - 1  # samples in the whole series
+    kinds = ("motion", "dct", "hist", "edge", "orb", "color")
+    part = np.zeros(len(kinds) + 1, np.float64)
+    if T > 0 and hi > lo:
+        c = pooling_weights(T, smoothing_factor)[lo:hi]
+        for k, kind in enumerate(kinds):
+            part[k] = float(np.dot(c, np.asarray(s[kind], np.float64)))
+        if T > 1:  # temporal sample j (global) belongs to per-frame sample j + 1
+            tl = max(lo, 1) - 1
+            ct = pooling_weights(T - 1, smoothing_factor)[tl:tl + len(s["temporal"])]
+            part[-1] = float(np.dot(ct, np.asarray(s["temporal"], np.float64)))
+    backend = td.get_backend(group)
+    t = torch.from_numpy(part)
+    if backend == "nccl":
+        t = t.cuda()
+    td.all_reduce(t, op=td.ReduceOp.SUM, group=group)
+    tot = t.cpu().numpy()
+    nan = float("nan")
+    vals = [float(v) if T > 0 else nan for v in tot[:len(kinds)]]
+    temporal = float(tot[-1]) if T > 1 else 0.0  # :541
+    frame_timestamps = extract_frame_timestamps(video_path, frame_interval, fps)
+    timestamp_pairs = list(zip(frame_timestamps[:-1], frame_timestamps[1:]))
+    fv = [process_frame_interval_for_parallel(p) for p in timestamp_pairs]
+    with np.errstate(invalid="ignore"), _quiet_empty_mean():
+        fpsv = np.mean(smooth_data(fv, smoothing_factor))
+    return (vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], temporal, fpsv)
 
 
 class _quiet_empty_mean:
