@@ -571,7 +571,11 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
                             unsigned *out_queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_canny_hyst_list, dim3(8, n), dim3(256), 0, st,
+    // workgroups per frame: ~64 tiles of the frame per 4-wave workgroup (1080p: 8, 2160p: 32)
+    const canny_geom g = canny_tiles(h, w);
+    int gx = (g.tiles_x * g.tiles_y + 63) / 64;
+    gx = gx < 8 ? 8 : (gx > 32 ? 32 : gx);
+    hipLaunchKernelGGL(k_canny_hyst_list, dim3(gx, n), dim3(256), 0, st,
                        make_hyst_args(strong, weak, h, w, out_queued, out_list, out_count, res), in_list, in_count,
                        in_queued);
 }

@@ -519,7 +519,10 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             // rounds 1..WIDE (still many tiles): wide grid over the per-frame lists; then the tail kernel
             // finishes every frame on its own workgroup with no host round-trip.
             prof_scope ps_(c, VQA_K_CANNY_HYST);
-            const int WIDE = 4;
+            // (a frame's tail runs on ONE workgroup: big frames in small batches get more wide rounds first)
+            const canny_geom cg = canny_tiles(ph, pw);
+            int WIDE = (cg.tiles_x * cg.tiles_y > 1024 && n < 256) ? 8 : 4;
+            if (const char *e = getenv("VQA_HYST_WIDE")) WIDE = atoi(e) > 0 ? atoi(e) : WIDE; // tuning knob
             for (round = 1; round <= WIDE; round++) {
                 const int in = round & 1, out = in ^ 1;
                 HIPCHK(c, hipMemsetAsync(counts + out * n, 0, sizeof(uint32_t) * n, st));
