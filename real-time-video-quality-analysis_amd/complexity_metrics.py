@@ -45,6 +45,18 @@ def get_engine(device=None):
     return _engines[device]
 
 
+_engine_pairs = {}
+
+
+def get_engine_pair(device=None):
+    """Two engines (= two HIP streams with their own staging buffers) on one device: while batch k's kernels
+    run on one, batch k+1 crosses PCIe on the other.  Used for host-resident clips longer than one batch."""
+    first = get_engine(device)
+    if first.device not in _engine_pairs:
+        _engine_pairs[first.device] = Engine(first.device)
+    return first, _engine_pairs[first.device]
+
+
 # ---------------------------------------------------------------------------
 # frame sources (replaces validate_video_path / read_frame_pairs / extract_frame_timestamps)
 # ---------------------------------------------------------------------------
@@ -323,14 +335,30 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
     out["range"] = (lo, hi)
     if len(idx) < 2 or hi <= lo:  # unopenable / too short: empty series, as the reference's empty pair list (:95-97)
         return out
-    eng = engine or get_engine()
-    params = eng.make_params(resize=(resize_width, resize_height), dct_mode=dct_mode)
+    on_device = isinstance(fr, DeviceFrames)
+    if engine is not None or on_device or len(idx) - 1 <= batch_size:
+        engs = [engine or get_engine()]
+    else:
+        engs = list(get_engine_pair())  # host clip, several batches: copy/compute ping-pong
+    params = engs[0].make_params(resize=(resize_width, resize_height), dct_mode=dct_mode)
     sel = idx[1 + lo:1 + hi]
     prev_i = idx[lo]
     first_global = lo == 0
-    for a in range(0, len(sel), batch_size):
+
+    def collect(eng, a):
+        rec = eng.complexity_wait()
+        for j, r in enumerate(rec):
+            for kind in ("motion", "dct", "hist", "edge", "orb", "color"):
+                if mask & _MASK[kind]:
+                    out[kind].append(_scalar(kind, r))
+            # the reference's first pair only primes prev_gray_frame (:533-537)
+            if (mask & N.M_TEMPORAL_DCT) and not (first_global and a == 0 and j == 0):
+                out["temporal"].append(_scalar("temporal", r))
+
+    pending = []
+    for k, a in enumerate(range(0, len(sel), batch_size)):
         chunk = sel[a:a + batch_size]
-        if isinstance(fr, DeviceFrames):
+        if on_device:
             # every frame_interval-th frame, zero-copy: the batch is a strided view of the resident clip
             batch = DeviceFrames(fr.ptr + int(chunk[0]) * fr.frame_stride, len(chunk), fr.h, fr.w,
                                  frame_stride=fr.frame_stride * frame_interval, row_stride=fr.row_stride,
@@ -339,15 +367,14 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
         else:
             batch = fr[int(chunk[0]):int(chunk[-1]) + 1:frame_interval]  # strided view: only selected frames are uploaded
             prev0 = np.asarray(fr[prev_i])
-        rec = eng.complexity(batch, prev0=prev0, mask=mask, params=params)
-        for j, r in enumerate(rec):
-            for kind in ("motion", "dct", "hist", "edge", "orb", "color"):
-                if mask & _MASK[kind]:
-                    out[kind].append(_scalar(kind, r))
-            # the reference's first pair only primes prev_gray_frame (:533-537)
-            if (mask & N.M_TEMPORAL_DCT) and not (first_global and a == 0 and j == 0):
-                out["temporal"].append(_scalar("temporal", r))
+        eng = engs[k % len(engs)]
+        if len(pending) == len(engs):
+            collect(*pending.pop(0))
+        eng.complexity_submit(batch, prev0, mask, params)
+        pending.append((eng, a))
         prev_i = chunk[-1]
+    while pending:
+        collect(*pending.pop(0))
     return out
 
 

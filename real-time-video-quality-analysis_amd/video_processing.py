@@ -16,7 +16,7 @@ import re
 import numpy as np
 
 from . import _native as N
-from .complexity_metrics import _open_frames, get_engine
+from .complexity_metrics import _open_frames, get_engine, get_engine_pair
 from .engine import DeviceFrames, bgr_planes, gray_planes, yuv420p_planes
 
 LAYOUTS = {
@@ -30,10 +30,10 @@ LAYOUTS = {
 def frame_quality(reference, distorted, layout="bgr24", ssim_mode="gauss", height=None, width=None, engine=None,
                   batch_size=64):
     """Per-frame SSE and SSIM per plane.  Returns (sse [n,p] uint64, ssim [n,p] float64, plane sizes)."""
-    eng = engine or get_engine()
     mode = {"gauss": N.SSIM_GAUSS, "ffmpeg": N.SSIM_FFMPEG}[ssim_mode]
     build, _ = LAYOUTS[layout]
-    if isinstance(reference, DeviceFrames):
+    on_device = isinstance(reference, DeviceFrames)
+    if on_device:
         h, w, n = reference.h, reference.w, reference.n
     else:
         reference = np.asarray(reference)
@@ -44,15 +44,27 @@ def frame_quality(reference, distorted, layout="bgr24", ssim_mode="gauss", heigh
         else:
             h, w = reference.shape[1], reference.shape[2]
     planes = build(h, w)
-    sse, ssim = [], []
-    for a in range(0, n, batch_size):
-        b = min(a + batch_size, n)
-        if isinstance(reference, DeviceFrames):
-            res = eng.quality(reference.slice(a, b), distorted.slice(a, b), planes, mode)
-        else:
-            res = eng.quality(reference[a:b], distorted[a:b], planes, mode)
+    # host streams longer than one batch: two engines ping-pong so batch k+1's copy overlaps batch k's kernels
+    engs = [engine or get_engine()] if (engine is not None or on_device or n <= batch_size) else list(get_engine_pair())
+    sse, ssim, pending = [], [], []
+
+    def collect(eng):
+        res = eng.quality_wait()
         sse.append(res["sse"])
         ssim.append(res["ssim"])
+
+    for k, a in enumerate(range(0, n, batch_size)):
+        b = min(a + batch_size, n)
+        eng = engs[k % len(engs)]
+        if len(pending) == len(engs):
+            collect(pending.pop(0))
+        if on_device:
+            eng.quality_submit(reference.slice(a, b), distorted.slice(a, b), planes, mode)
+        else:
+            eng.quality_submit(reference[a:b], distorted[a:b], planes, mode)
+        pending.append(eng)
+    while pending:
+        collect(pending.pop(0))
     sizes = [(p[0], p[1]) for p in planes]
     return np.concatenate(sse), np.concatenate(ssim), sizes
 

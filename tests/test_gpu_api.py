@@ -176,3 +176,22 @@ def test_sharded_stream_on_gpu_equals_single_process(tmp_path, n, interval, resi
         got = np.load(out % r)
         for k in range(8):
             assert abs(got[k] - want[k]) <= 1e-12 * max(abs(want[k]), 1e-30), (r, k, got[k], want[k])
+
+
+def test_host_clip_batches_pipeline_over_two_engines():
+    """Host clips longer than one batch ping-pong over two engines (copy/compute overlap): same numbers,
+    same order as the one-engine path."""
+    from rtvqa_amd import complexity_metrics as cm
+    from rtvqa_amd import video_processing as vp
+    from rtvqa_amd import synth
+    clip = _clip(40, 120, 160, seed=12)
+    one = cm.complexity_series(clip, 64, 64, frame_interval=1, batch_size=7, engine=cm.get_engine())
+    two = cm.complexity_series(clip, 64, 64, frame_interval=1, batch_size=7)
+    big = cm.complexity_series(clip, 64, 64, frame_interval=1, batch_size=100)
+    for k in ("motion", "dct", "hist", "edge", "orb", "color", "temporal"):
+        assert len(one[k]) == len(two[k]) == len(big[k]) == (38 if k == "temporal" else 39)
+        assert all(a == b == c for a, b, c in zip(one[k], two[k], big[k])), k
+    dist = synth.distort(clip)
+    s1 = vp.frame_quality(clip, dist, "bgr24", "gauss", batch_size=6, engine=cm.get_engine())
+    s2 = vp.frame_quality(clip, dist, "bgr24", "gauss", batch_size=6)
+    assert (s1[0] == s2[0]).all() and (s1[1] == s2[1]).all() and s1[0].shape == (40, 3)
