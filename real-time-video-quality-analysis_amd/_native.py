@@ -31,8 +31,8 @@ M_MOTION = 1 << 5
 M_ORB = 1 << 6
 M_ALL = 0x7F
 
-(K_GRAY_HIST, K_RESIZE, K_DCT8, K_DCT_FULL, K_CANNY_NMS, K_CANNY_HYST, K_SAD, K_SSIM_GAUSS, K_SSIM_FFMPEG,
- K_COUNT) = range(10)
+(K_GRAY_HIST, K_RESIZE, K_DCT8, K_DCT_FULL, K_CANNY_NMS, K_CANNY_HYST, K_SAD, K_SSIM_GAUSS, K_SSIM_FFMPEG, K_ORB,
+ K_COUNT) = range(11)
 
 DCT_AUTO, DCT_BLOCK8, DCT_FULL = 0, 1, 2
 SSIM_GAUSS, SSIM_FFMPEG = 0, 1

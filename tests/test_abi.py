@@ -55,6 +55,26 @@ int main(void){
         assert FRAME_DTYPE.fields[name][1] == getattr(N.VqaFrameMetrics, name).offset, name
 
 
+def test_constants_match_header():
+    """Mask bits, modes, status codes and kernel ids of the ctypes binding are the header's."""
+    from rtvqa_amd import _native as N
+    txt = open(os.path.join(REPO, "include", "vqa.h")).read()
+    for name, expr in re.findall(r"^#define\s+VQA_(M_\w+|DCT_\w+|SSIM_\w+|ABI_VERSION)\s+(\(?[0-9xA-Fa-fuU <]+\)?)", txt, flags=re.M):
+        val = eval(re.sub(r"(?<=[0-9a-fA-F])[uU]", "", expr))
+        assert getattr(N, "VQA_ABI_VERSION" if name == "ABI_VERSION" else name) == val, name
+    enum = re.search(r"enum vqa_kernel_id \{(.*?)\}", txt, flags=re.S).group(1)
+    ids = dict((k, int(v)) for k, v in re.findall(r"VQA_(K_\w+)\s*=\s*(\d+)", enum))
+    assert len(ids) >= 10
+    for k, v in ids.items():
+        assert getattr(N, k) == v, k
+    lib = N.load()
+    lib.vqa_kernel_name.restype = C.c_char_p
+    names = [lib.vqa_kernel_name(i).decode() for i in range(N.K_COUNT)]
+    assert len(set(names)) == N.K_COUNT and "?" not in names
+    for k, v in re.findall(r"VQA_(ERR_\w+|OK)\s*=\s*(-?\d+)", txt):
+        assert getattr(N, "VQA_" + k) == int(v), k
+
+
 def test_error_paths_without_compute():
     from rtvqa_amd import _native as N
     lib = N.load()
