@@ -153,7 +153,8 @@ VQA_API void *vqa_stream(vqa_ctx *ctx);
  * inside larger frames; only the 3*w bytes of each row are ever read).
  * prev0: the frame preceding frames[0] (same geometry, row_stride and
  * mem_kind) or NULL; frame i's "previous" is frame i-1.
- * Asynchronous: returns once the work is enqueued.                           */
+ * Asynchronous: returns once the work is enqueued.  Limits: n <= 65535 frames
+ * per call, h*w <= 2^28 pixels (VQA_ERR_UNSUPPORTED beyond).                  */
 VQA_API int vqa_complexity_submit(vqa_ctx *ctx, const uint8_t *frames, const uint8_t *prev0, int mem_kind,
                           int n, int h, int w, int64_t frame_stride, int64_t row_stride,
                           uint32_t metric_mask, const vqa_params *params);

@@ -350,6 +350,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     if (P.resize_w < 0 || P.resize_h < 0 || ((P.resize_w == 0) != (P.resize_h == 0))) return VQA_ERR_INVALID;
     if (P.dct_mode < VQA_DCT_AUTO || P.dct_mode > VQA_DCT_FULL) return VQA_ERR_INVALID;
     if ((int64_t)h * w > (1ll << 28)) return VQA_ERR_UNSUPPORTED;
+    if (n > 65535) return VQA_ERR_UNSUPPORTED; // frames ride in gridDim.y: split larger batches in the caller
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
 
@@ -573,6 +574,7 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
     if (!c || !ref || !dist || n <= 0 || !planes || n_planes <= 0 || n_planes > 4) return VQA_ERR_INVALID;
     if (mem_kind != VQA_MEM_HOST && mem_kind != VQA_MEM_DEVICE) return VQA_ERR_INVALID;
     if (ssim_mode != VQA_SSIM_GAUSS && ssim_mode != VQA_SSIM_FFMPEG) return VQA_ERR_INVALID;
+    if (n > 65535) return VQA_ERR_UNSUPPORTED; // frames ride in gridDim.y: split larger batches in the caller
     if (c->pend_q) return VQA_ERR_STATE;
     int64_t span = 0;
     int maxblocks = 1;

@@ -195,3 +195,37 @@ def test_host_clip_batches_pipeline_over_two_engines():
     s1 = vp.frame_quality(clip, dist, "bgr24", "gauss", batch_size=6, engine=cm.get_engine())
     s2 = vp.frame_quality(clip, dist, "bgr24", "gauss", batch_size=6)
     assert (s1[0] == s2[0]).all() and (s1[1] == s2[1]).all() and s1[0].shape == (40, 3)
+
+
+def test_two_engines_from_two_threads():
+    """One ctx per host thread (include/vqa.h): two threads, each with its own engine on the same device,
+    running different work concurrently, get the results a single thread gets."""
+    import threading
+    import rtvqa_amd
+    from rtvqa_amd import _native as N
+    from rtvqa_amd import synth
+    from rtvqa_amd.engine import bgr_planes
+    clips = [_clip(9, 144, 256, seed=31), _clip(9, 90, 130, seed=32)]
+    dists = [synth.distort(c) for c in clips]
+
+    def work(eng, k):
+        c, d = clips[k], dists[k]
+        rec = eng.complexity(d[1:], prev0=d[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        q = eng.quality(c, d, bgr_planes(c.shape[1], c.shape[2]), N.SSIM_GAUSS)
+        return rec.tobytes(), q.tobytes()
+
+    with rtvqa_amd.Engine(0) as e0, rtvqa_amd.Engine(0) as e1:
+        want = [work(e0, 0), work(e0, 1)]
+        got = [[None] * 6, [None] * 6]
+
+        def loop(eng, k):
+            for it in range(6):
+                got[k][it] = work(eng, k)
+
+        ts = [threading.Thread(target=loop, args=(e, k)) for k, e in enumerate((e0, e1))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    for k in range(2):
+        assert all(g == want[k] for g in got[k]), k
