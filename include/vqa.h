@@ -39,7 +39,7 @@ extern "C" {
 #define VQA_API
 #endif
 
-#define VQA_ABI_VERSION 2
+#define VQA_ABI_VERSION 3
 
 typedef enum vqa_status {
     VQA_OK = 0,
@@ -76,6 +76,11 @@ typedef enum vqa_mem_kind {
 #define VQA_DCT_BLOCK8 1 /* 8x8 block DCT-II (north_star).  Energy == full-frame energy     */
 #define VQA_DCT_FULL   2 /* one full-frame DCT-II, exactly what cv2.dct computes            */
 
+/* motion_mode (what VQA_M_MOTION computes) */
+#define VQA_MOTION_SAD       0 /* 16x16 block-SAD full search (north_star; default)          */
+#define VQA_MOTION_FARNEBACK 1 /* cv2.calcOpticalFlowFarneback(.., 0.5, 3, 15, 3, 5, 1.2, 0)
+                                  mean magnitude — what the reference computes (:340-343)     */
+
 /* ssim_mode */
 #define VQA_SSIM_GAUSS  0 /* 11x11 Gaussian window, sigma 1.5 (north_star)                  */
 #define VQA_SSIM_FFMPEG 1 /* FFmpeg vf_ssim: integer 8x8 window, stride 4 (what the
@@ -86,7 +91,8 @@ typedef struct vqa_params {
     int32_t canny_low, canny_high; /* cv2.Canny thresholds; reference uses 100, 200 (:503)  */
     int32_t sad_range;          /* block-SAD search radius R, 0..7 (default 7)              */
     int32_t dct_mode;           /* VQA_DCT_*                                                */
-    int32_t reserved[10];       /* must be zero                                             */
+    int32_t motion_mode;        /* VQA_MOTION_*                                             */
+    int32_t reserved[9];        /* must be zero                                             */
 } vqa_params;
 
 /* Per-frame results of the complexity kernels.  Integer fields are exact
@@ -107,6 +113,7 @@ typedef struct vqa_frame_metrics {
     uint32_t hyst_steps;         /* diagnostics: relaxation steps summed over this frame's tiles       */
     uint32_t orb_keypoints;      /* len(ORB_create().detectAndCompute(gray64)[0])  (:385-389)  */
     uint32_t orb_response;       /* FAST score of that keypoint, 0 when there is none       */
+    double   flow_mag_mean;      /* VQA_MOTION_FARNEBACK: np.mean(|flow|) (:342-343); else 0 */
 } vqa_frame_metrics;
 
 /* One 8-bit plane inside a frame buffer (planar YUV plane, or one channel of
@@ -181,7 +188,8 @@ enum vqa_kernel_id {
     VQA_K_SSIM_GAUSS = 7,
     VQA_K_SSIM_FFMPEG = 8,
     VQA_K_ORB = 9,       /* FAST-9/16 + NMS on the 64x64 thumbnail's centre */
-    VQA_K_COUNT = 10
+    VQA_K_FARNEBACK = 10, /* the whole Farneback pyramid (about 45 launches per chunk of pairs) */
+    VQA_K_COUNT = 11
 };
 /* When enabled, every kernel launch made by a submit call is bracketed by a
  * hipEvent pair recorded on the ctx stream; the elapsed times are accumulated

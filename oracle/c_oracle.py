@@ -63,6 +63,11 @@ def lib():
         L.vqo_fast9.restype = C.c_long
         L.vqo_orb64_count.argtypes = [u8p, C.c_ssize_t, C.POINTER(C.c_int)]
         L.vqo_orb64_count.restype = C.c_int
+        L.vqo_farneback_mean_mag.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_ssize_t, C.POINTER(C.c_float)]
+        L.vqo_farneback_mean_mag.restype = C.c_double
+        L.vqo_fb_prepare.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.vqo_fb_prepare.restype = None
         _lib = L
     return _lib
 
@@ -219,3 +224,24 @@ def orb64_count(gray64):
     if n < 0:
         raise MemoryError
     return n, r.value
+
+
+def farneback(prev, curr, want_flow=False):
+    """np.mean(|cv2.calcOpticalFlowFarneback(prev, curr, None, 0.5, 3, 15, 3, 5, 1.2, 0)|) (:340-343)."""
+    prev, curr = _c(prev), _c(curr)
+    h, w = curr.shape
+    flow = np.zeros((h, w, 2), np.float32) if want_flow else None
+    m = lib().vqo_farneback_mean_mag(_u8(prev), _u8(curr), h, w, w,
+                                     flow.ctypes.data_as(C.POINTER(C.c_float)) if want_flow else None)
+    if m < 0:
+        raise MemoryError
+    return (m, flow) if want_flow else m
+
+
+def fb_prepare(n=5, sigma=1.2):
+    g, xg, xxg = (np.zeros(2 * n + 1, np.float32) for _ in range(3))
+    ig = np.zeros(4, np.float64)
+    fp = C.POINTER(C.c_float)
+    lib().vqo_fb_prepare(n, sigma, g.ctypes.data_as(fp), xg.ctypes.data_as(fp), xxg.ctypes.data_as(fp),
+                         ig.ctypes.data_as(C.POINTER(C.c_double)))
+    return g, xg, xxg, ig

@@ -283,3 +283,136 @@ def orb64_count(gray64, threshold=20):
     """ORB keypoint count of a 64x64 image (see oracle/vqa_oracle.c vqo_orb64_count)."""
     keep = fast9_nms(fast9_scores(gray64, threshold))
     return int(keep[31:33, 31:33].sum())
+
+
+# ---------------------------------------------------------------------------
+# Farneback dense flow, vectorised in float64 with scipy.ndimage: an independent
+# restatement of oracle/vqa_oracle.c's vqo_farneback_mean_mag (same published
+# algorithm, different code shape, no float32 rounding) for cross-checking.
+# ---------------------------------------------------------------------------
+def _fb_resize(img, dh, dw):
+    img = np.asarray(img, np.float64)
+    sh, sw = img.shape[:2]
+    if (sh, sw) == (dh, dw):
+        return img.copy()
+    if sh == 2 * dh and sw == 2 * dw:
+        return (img[0::2, 0::2] + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2]) * 0.25
+
+    def axis(ssize, dsize, is_x):
+        f = ((np.arange(dsize) + 0.5) * (1.0 / (dsize / ssize)) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s).astype(np.float64)
+        if is_x:
+            f[s < 0] = 0
+            s[s < 0] = 0
+            f[s >= ssize - 1] = 0
+            s[s >= ssize - 1] = ssize - 1
+        return s, f
+    xs, xf = axis(sw, dw, True)
+    ys, yf = axis(sh, dh, False)
+    x0, x1 = xs, np.minimum(xs + 1, sw - 1)
+    y0, y1 = np.clip(ys, 0, sh - 1), np.clip(ys + 1, 0, sh - 1)
+    sh_ = (1, dw) + (1,) * (img.ndim - 2)
+    xf_, yf_ = xf.reshape(sh_), yf.reshape((dh, 1) + (1,) * (img.ndim - 2))
+    r0 = img[y0][:, x0] * (1 - xf_) + img[y0][:, x1] * xf_
+    r1 = img[y1][:, x0] * (1 - xf_) + img[y1][:, x1] * xf_
+    return r0 * (1 - yf_) + r1 * yf_
+
+
+def farneback_mean_mag(prev, curr, want_flow=False):
+    import scipy.ndimage as ndi
+    prev, curr = np.asarray(prev, np.float64), np.asarray(curr, np.float64)
+    h, w = curr.shape
+    levels, scale = 0, 1.0
+    for k in range(3):
+        scale *= 0.5
+        if w * scale < 32 or h * scale < 32:
+            break
+        levels = k + 1
+    n = 5
+    x = np.arange(-n, n + 1, dtype=np.float64)
+    g = np.exp(-x * x / (2 * 1.2 * 1.2)).astype(np.float32).astype(np.float64)
+    g = (g / g.sum()).astype(np.float32).astype(np.float64)
+    xg, xxg = (x * g).astype(np.float32).astype(np.float64), (x * x * g).astype(np.float32).astype(np.float64)
+    G = np.zeros((6, 6))
+    gg = np.outer(g, g)
+    X, Y = np.meshgrid(x, x)
+    G[0, 0], G[1, 1], G[3, 3], G[5, 5] = gg.sum(), (gg * X * X).sum(), (gg * X ** 4).sum(), (gg * X * X * Y * Y).sum()
+    G[2, 2] = G[0, 3] = G[0, 4] = G[3, 0] = G[4, 0] = G[1, 1]
+    G[4, 4] = G[3, 3]
+    G[3, 4] = G[4, 3] = G[5, 5]
+    iG = np.linalg.inv(G)
+    ig11, ig03, ig33, ig55 = iG[1, 1], iG[0, 3], iG[3, 3], iG[5, 5]
+
+    def polyexp(I):
+        c = lambda a, k, ax: ndi.correlate1d(a, k, axis=ax, mode="nearest")
+        r0, r1, r2 = c(I, g, 0), c(I, xg, 0), c(I, xxg, 0)
+        b1, b2, b3 = c(r0, g, 1), c(r0, xg, 1), c(r1, g, 1)
+        b4, b5, b6 = c(r0, xxg, 1), c(r2, g, 1), c(r1, xg, 1)
+        return np.stack([b3 * ig11, b2 * ig11, b1 * ig03 + b5 * ig33, b1 * ig03 + b4 * ig33, b6 * ig55], -1)
+
+    border = np.array([0.14, 0.14, 0.4472, 0.4472, 0.4472], np.float32).astype(np.float64)
+
+    def update(R0, R1, flow):
+        hh, ww = flow.shape[:2]
+        yy, xx = np.mgrid[0:hh, 0:ww]
+        dx, dy = flow[..., 0], flow[..., 1]
+        fx, fy = (xx + dx).astype(np.float32).astype(np.float64), (yy + dy).astype(np.float32).astype(np.float64)
+        x1, y1 = np.floor(fx).astype(np.int64), np.floor(fy).astype(np.int64)
+        fx, fy = fx - x1, fy - y1
+        ok = (x1 >= 0) & (x1 < ww - 1) & (y1 >= 0) & (y1 < hh - 1)
+        xc, yc = np.clip(x1, 0, ww - 2), np.clip(y1, 0, hh - 2)
+        a00, a01, a10, a11 = ((1 - fx) * (1 - fy))[..., None], (fx * (1 - fy))[..., None], ((1 - fx) * fy)[..., None], (fx * fy)[..., None]
+        rr = a00 * R1[yc, xc] + a01 * R1[yc, xc + 1] + a10 * R1[yc + 1, xc] + a11 * R1[yc + 1, xc + 1]
+        o = ok
+        r2 = np.where(o, rr[..., 0], 0.0)
+        r3 = np.where(o, rr[..., 1], 0.0)
+        r4 = np.where(o, (R0[..., 2] + rr[..., 2]) * 0.5, R0[..., 2])
+        r5 = np.where(o, (R0[..., 3] + rr[..., 3]) * 0.5, R0[..., 3])
+        r6 = np.where(o, (R0[..., 4] + rr[..., 4]) * 0.25, R0[..., 4] * 0.5)
+        r2 = (R0[..., 0] - r2) * 0.5
+        r3 = (R0[..., 1] - r3) * 0.5
+        r2 = r2 + r4 * dy + r6 * dx
+        r3 = r3 + r6 * dy + r5 * dx
+        sx, sy = np.ones(ww), np.ones(hh)
+        for i in range(min(5, ww)):
+            sx[i] *= border[i]
+            sx[ww - 1 - i] *= border[i]
+        for i in range(min(5, hh)):
+            sy[i] *= border[i]
+            sy[hh - 1 - i] *= border[i]
+        sc = np.outer(sy, sx)
+        r2, r3, r4, r5, r6 = r2 * sc, r3 * sc, r4 * sc, r5 * sc, r6 * sc
+        return np.stack([r4 * r4 + r6 * r6, (r4 + r5) * r6, r5 * r5 + r6 * r6, r4 * r2 + r6 * r3, r6 * r2 + r5 * r3], -1)
+
+    def blur_solve(M):
+        ones = np.ones(15)
+        v = ndi.correlate1d(ndi.correlate1d(M, ones, axis=0, mode="nearest"), ones, axis=1, mode="nearest") / 225.0
+        idet = 1.0 / (v[..., 0] * v[..., 2] - v[..., 1] ** 2 + 1e-3)
+        return np.stack([(v[..., 0] * v[..., 4] - v[..., 1] * v[..., 3]) * idet,
+                         (v[..., 2] * v[..., 3] - v[..., 1] * v[..., 4]) * idet], -1)
+
+    flow = None
+    for k in range(levels, -1, -1):
+        scale = 0.5 ** k
+        sigma = (1.0 / scale - 1) * 0.5
+        ks = max(int(np.rint(sigma * 5)) | 1, 3)
+        lw, lh = int(np.rint(w * scale)), int(np.rint(h * scale))
+        if sigma <= 0:
+            kern = np.array([0.25, 0.5, 0.25])
+        else:
+            t = np.arange(ks) - ks // 2
+            kern = np.exp(-0.5 * t * t / (sigma * sigma))
+            kern = (kern / kern.sum()).astype(np.float32).astype(np.float64)
+        flow = np.zeros((lh, lw, 2)) if flow is None else _fb_resize(flow, lh, lw) * 2.0
+        R = []
+        for img in (prev, curr):
+            b = ndi.correlate1d(ndi.correlate1d(img, kern, axis=1, mode="mirror"), kern, axis=0, mode="mirror")
+            R.append(polyexp(_fb_resize(b, lh, lw)))
+        M = update(R[0], R[1], flow)
+        for i in range(3):
+            flow = blur_solve(M)
+            if i < 2:
+                M = update(R[0], R[1], flow)
+    mag = np.sqrt(flow[..., 0] ** 2 + flow[..., 1] ** 2)
+    return (float(mag.mean()), flow) if want_flow else float(mag.mean())

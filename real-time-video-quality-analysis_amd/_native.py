@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvqa_hip.so")
 
-VQA_ABI_VERSION = 2
+VQA_ABI_VERSION = 3
 
 VQA_OK = 0
 VQA_ERR_INVALID = -1
@@ -32,17 +32,18 @@ M_ORB = 1 << 6
 M_ALL = 0x7F
 
 (K_GRAY_HIST, K_RESIZE, K_DCT8, K_DCT_FULL, K_CANNY_NMS, K_CANNY_HYST, K_SAD, K_SSIM_GAUSS, K_SSIM_FFMPEG, K_ORB,
- K_COUNT) = range(11)
+ K_FARNEBACK, K_COUNT) = range(12)
 
 DCT_AUTO, DCT_BLOCK8, DCT_FULL = 0, 1, 2
 SSIM_GAUSS, SSIM_FFMPEG = 0, 1
+MOTION_SAD, MOTION_FARNEBACK = 0, 1
 
 
 class VqaParams(C.Structure):
     _fields_ = [("resize_w", C.c_int32), ("resize_h", C.c_int32),
                 ("canny_low", C.c_int32), ("canny_high", C.c_int32),
                 ("sad_range", C.c_int32), ("dct_mode", C.c_int32),
-                ("reserved", C.c_int32 * 10)]
+                ("motion_mode", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
 class VqaFrameMetrics(C.Structure):
@@ -58,7 +59,8 @@ class VqaFrameMetrics(C.Structure):
                 ("edge_strong", C.c_uint32),
                 ("edge_weak", C.c_uint32),
                 ("has_prev", C.c_uint32),
-                ("hyst_steps", C.c_uint32), ("orb_keypoints", C.c_uint32), ("orb_response", C.c_uint32)]
+                ("hyst_steps", C.c_uint32), ("orb_keypoints", C.c_uint32), ("orb_response", C.c_uint32),
+                ("flow_mag_mean", C.c_double)]
 
 
 class VqaPlaneDesc(C.Structure):

@@ -47,7 +47,9 @@ struct vqa_ctx {
     void *qres_host = nullptr; size_t qres_host_cap = 0;
 
     std::map<std::tuple<int, int, int, int>, resize_tabs> tabs;
+    std::map<std::tuple<int, int, int, int>, fb_resize_tabs> fb_tabs;
     std::map<int, float *> dct_mats;
+    dbuf fb_tmp, fb_blur, fb_img, fb_R, fb_M, fb_flow0, fb_flow1, fb_part;
 
     // pending work
     int pend_c = 0, pend_q = 0;
@@ -205,6 +207,168 @@ static int get_dct_matrix(vqa_ctx *c, int n, float **out)
     return VQA_OK;
 }
 
+// ---- Farneback (k_farneback.hip): host-side constants, tables and the level loop ---------------------
+// getGaussianKernel(ksize, sigma, CV_32F): taps formed and normalised in double, rounded to float; the
+// fixed 1/4,1/2,1/4 kernel when sigma == 0 (restated independently of the oracle's copy)
+static fb_taps fb_gauss_taps(int ksize, double sigma)
+{
+    fb_taps T;
+    memset(&T, 0, sizeof T);
+    T.ksize = ksize;
+    if (sigma <= 0 && ksize == 3) { T.k[0] = 0.25f; T.k[1] = 0.5f; T.k[2] = 0.25f; return T; }
+    double kd[32], sum = 0;
+    const int r = ksize / 2;
+    const double sc = -0.5 / (sigma * sigma);
+    for (int i = 0; i < ksize; i++) { const double x = i - r; kd[i] = std::exp(sc * x * x); sum += kd[i]; }
+    for (int i = 0; i < ksize; i++) T.k[i] = (float)(kd[i] / sum);
+    return T;
+}
+
+// FarnebackPrepareGaussian(5, 1.2): taps and the four needed entries of inv(G) (G is block-sparse: closed form)
+static fb_poly fb_poly_consts()
+{
+    fb_poly C;
+    const int n = 5;
+    const double sigma = 1.2;
+    double s = 0;
+    for (int x = -n; x <= n; x++) { C.g[x + n] = (float)std::exp(-x * x / (2 * sigma * sigma)); s += C.g[x + n]; }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        C.g[x + n] = (float)(C.g[x + n] * s);
+        C.xg[x + n] = (float)(x * C.g[x + n]);
+        C.xxg[x + n] = (float)(x * x * C.g[x + n]);
+    }
+    double a = 0, b = 0, c = 0, d = 0;
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            const double gg = (double)C.g[y + n] * C.g[x + n];
+            a += gg; b += gg * x * x; c += gg * x * x * x * x; d += gg * x * x * y * y;
+        }
+    const double det = a * (c * c - d * d) - 2 * b * b * (c - d);
+    C.ig11 = 1. / b;
+    C.ig03 = -b * (c - d) / det;
+    C.ig33 = (a * c - b * b) / det;
+    C.ig55 = 1. / d;
+    return C;
+}
+
+static void fb_build_axis(int ssize, int dsize, bool is_x, std::vector<int32_t> &ofs, std::vector<float> &coef)
+{
+    ofs.resize(dsize);
+    coef.resize(2 * (size_t)dsize);
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= (float)s;
+        if (is_x) {
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+        }
+        ofs[d] = s;
+        coef[2 * (size_t)d] = 1.f - f;
+        coef[2 * (size_t)d + 1] = f;
+    }
+}
+
+static int get_fb_tabs(vqa_ctx *c, int sh, int sw, int dh, int dw, fb_resize_tabs &out)
+{
+    auto key = std::make_tuple(sh, sw, dh, dw);
+    auto it = c->fb_tabs.find(key);
+    if (it != c->fb_tabs.end()) { out = it->second; return VQA_OK; }
+    fb_resize_tabs t;
+    t.mode = (sw == 2 * dw && sh == 2 * dh) ? 1 : 0;
+    std::vector<int32_t> xo, yo;
+    std::vector<float> xa, yb;
+    fb_build_axis(sw, dw, true, xo, xa);
+    fb_build_axis(sh, dh, false, yo, yb);
+    HIPCHK(c, hipMalloc((void **)&t.xofs, sizeof(int32_t) * dw));
+    HIPCHK(c, hipMalloc((void **)&t.xa, sizeof(float) * 2 * dw));
+    HIPCHK(c, hipMalloc((void **)&t.yofs, sizeof(int32_t) * dh));
+    HIPCHK(c, hipMalloc((void **)&t.yb, sizeof(float) * 2 * dh));
+    HIPCHK(c, hipMemcpy(t.xofs, xo.data(), sizeof(int32_t) * dw, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(t.xa, xa.data(), sizeof(float) * 2 * dw, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(t.yofs, yo.data(), sizeof(int32_t) * dh, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(t.yb, yb.data(), sizeof(float) * 2 * dh, hipMemcpyHostToDevice));
+    c->fb_tabs[key] = t;
+    out = t;
+    return VQA_OK;
+}
+
+// gray: n + 1 planes (slot 0 = the frame before the batch); pair i = planes i, i + 1 -> res[i].flow_mag_mean.
+// Pairs are processed in chunks whose planes (expansions: 20 B/pixel) stay resident in a bounded scratch.
+static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp, int64_t plane_stride, int n, int h,
+                         int w, bool first_has_prev, vqa_frame_metrics *res)
+{
+    const double pyr_scale = 0.5;
+    const int iters = 3, min_size = 32;
+    int levels = 3, k;
+    double scale = 1;
+    for (k = 0; k < levels; k++) {
+        scale *= pyr_scale;
+        if (w * scale < min_size || h * scale < min_size) break;
+    }
+    levels = k;
+    const fb_poly PC = fb_poly_consts();
+    const size_t P = (size_t)h * w;
+    // per pair ~72 B/pixel of scratch (planes: blur tmp 4 + blurred 4 + level image 4 + expansion 20; pairs:
+    // products 20 + two flow fields 16); keep a chunk under ~3 GiB
+    int mc = (int)((3ull << 30) / (72 * P));
+    mc = mc < 1 ? 1 : (mc > n ? n : mc);
+    int rc;
+    if ((rc = ensure(c, c->fb_tmp, sizeof(float) * P * (mc + 1)))) return rc;
+    if ((rc = ensure(c, c->fb_blur, sizeof(float) * P * (mc + 1)))) return rc;
+    if ((rc = ensure(c, c->fb_img, sizeof(float) * P * (mc + 1)))) return rc;
+    if ((rc = ensure(c, c->fb_R, sizeof(float) * 5 * P * (mc + 1)))) return rc;
+    if ((rc = ensure(c, c->fb_M, sizeof(float) * 5 * P * mc))) return rc;
+    if ((rc = ensure(c, c->fb_flow0, sizeof(float) * 2 * P * mc))) return rc;
+    if ((rc = ensure(c, c->fb_flow1, sizeof(float) * 2 * P * mc))) return rc;
+    if ((rc = ensure(c, c->fb_part, sizeof(double) * fb_mag_blocks() * mc))) return rc;
+    float *tmp = (float *)c->fb_tmp.p, *blur = (float *)c->fb_blur.p, *img = (float *)c->fb_img.p;
+    float *R = (float *)c->fb_R.p, *M = (float *)c->fb_M.p;
+    float *flow = (float *)c->fb_flow0.p, *prev_flow = (float *)c->fb_flow1.p;
+    for (int a = 0; a < n; a += mc) {
+        const int pairs = (n - a) < mc ? (n - a) : mc, planes = pairs + 1;
+        const uint8_t *g0 = gray + (int64_t)a * plane_stride;
+        int pw = 0, ph = 0;
+        for (k = levels; k >= 0; k--) {
+            scale = 1;
+            for (int i = 0; i < k; i++) scale *= pyr_scale;
+            const double sigma = (1. / scale - 1) * 0.5;
+            int smooth_sz = (int)std::lrint(sigma * 5) | 1;
+            if (smooth_sz < 3) smooth_sz = 3;
+            const int lw = (int)std::lrint(w * scale), lh = (int)std::lrint(h * scale);
+            // flow of this level: zero at the coarsest, else the coarser level's flow resized and doubled
+            if (k == levels) {
+                HIPCHK(c, hipMemsetAsync(flow, 0, sizeof(float) * 2 * (size_t)lw * lh * pairs, st));
+            } else {
+                fb_resize_tabs T;
+                if ((rc = get_fb_tabs(c, ph, pw, lh, lw, T))) return rc;
+                launch_fb_resize(st, prev_flow, ph, pw, 2, flow, lh, lw, pairs, T, (float)(1. / pyr_scale), true);
+            }
+            // every plane once: blur at full resolution, resize to the level, polynomial expansion
+            launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, fb_gauss_taps(smooth_sz, sigma), tmp, blur);
+            const float *level_img = blur;
+            if (lw != w || lh != h) {
+                fb_resize_tabs T;
+                if ((rc = get_fb_tabs(c, h, w, lh, lw, T))) return rc;
+                launch_fb_resize(st, blur, h, w, 1, img, lh, lw, planes, T, 1.f, false);
+                level_img = img;
+            }
+            launch_fb_polyexp(st, level_img, planes, lh, lw, PC, R);
+            launch_fb_update(st, R, flow, pairs, lh, lw, M);
+            for (int i = 0; i < iters; i++) {
+                launch_fb_blur_solve(st, M, pairs, lh, lw, flow);
+                if (i < iters - 1) launch_fb_update(st, R, flow, pairs, lh, lw, M);
+            }
+            float *t = flow; flow = prev_flow; prev_flow = t; // prev_flow = this level's result
+            pw = lw; ph = lh;
+        }
+        launch_fb_mag(st, prev_flow, pairs, h, w, (double *)c->fb_part.p, a > 0 || first_has_prev, res + a);
+    }
+    return VQA_OK;
+}
+
 extern "C" {
 
 int vqa_abi_version(void) { return VQA_ABI_VERSION; }
@@ -267,10 +431,14 @@ int vqa_destroy(vqa_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     dbuf *bufs[] = {&c->gray_full, &c->planeA, &c->planeB, &c->state, &c->res_dev, &c->partials, &c->tile_flags,
                     &c->dirty0, &c->dirty1, &c->again_dev, &c->stage_frames, &c->stage_prev, &c->dct_scratch,
-                    &c->dct_pe, &c->dct_pt, &c->qres_dev, &c->qpartials, &c->qstage_ref, &c->qstage_dist};
+                    &c->dct_pe, &c->dct_pt, &c->qres_dev, &c->qpartials, &c->qstage_ref, &c->qstage_dist,
+                    &c->fb_tmp, &c->fb_blur, &c->fb_img, &c->fb_R, &c->fb_M, &c->fb_flow0, &c->fb_flow1, &c->fb_part};
     for (dbuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &kv : c->tabs) {
+        (void)hipFree(kv.second.xofs); (void)hipFree(kv.second.xa); (void)hipFree(kv.second.yofs); (void)hipFree(kv.second.yb);
+    }
+    for (auto &kv : c->fb_tabs) {
         (void)hipFree(kv.second.xofs); (void)hipFree(kv.second.xa); (void)hipFree(kv.second.yofs); (void)hipFree(kv.second.yb);
     }
     for (auto &kv : c->dct_mats) (void)hipFree(kv.second);
@@ -344,8 +512,9 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     if (c->pend_c) return VQA_ERR_STATE;
     vqa_params P;
     if (params) P = *params; else vqa_default_params(&P);
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < 9; i++)
         if (P.reserved[i]) return VQA_ERR_INVALID;
+    if (P.motion_mode != VQA_MOTION_SAD && P.motion_mode != VQA_MOTION_FARNEBACK) return VQA_ERR_INVALID;
     if (P.sad_range < 0 || P.sad_range > 7) return VQA_ERR_INVALID;
     if (P.resize_w < 0 || P.resize_h < 0 || ((P.resize_w == 0) != (P.resize_h == 0))) return VQA_ERR_INVALID;
     if (P.dct_mode < VQA_DCT_AUTO || P.dct_mode > VQA_DCT_FULL) return VQA_ERR_INVALID;
@@ -475,10 +644,15 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         }
     }
 
-    // ---- block-SAD motion (full-resolution gray)
-    if (want_m) {
+    // ---- motion on the full-resolution gray planes (the reference never resizes for it, :327-328):
+    // block-SAD (north_star) or the reference's own Farneback flow
+    if (want_m && P.motion_mode == VQA_MOTION_SAD) {
         prof_scope ps_(c, VQA_K_SAD);
         launch_block_sad(st, gfull, gp, full_stride, n, h, w, P.sad_range, has_prev0, res);
+    } else if (want_m) {
+        prof_scope ps_(c, VQA_K_FARNEBACK);
+        rc = run_farneback(c, st, gfull, gp, full_stride, n, h, w, has_prev0, res);
+        if (rc) return rc;
     }
 
     // ---- Canny (input: plane B)
@@ -679,7 +853,7 @@ const char *vqa_kernel_name(int id)
 {
     static const char *names[VQA_K_COUNT] = {"k_bgr2gray_hist", "k_resize_planes", "k_dct8", "k_dct_full(gemm_nt x4)",
                                              "k_canny_nms", "k_canny_hyst", "k_block_sad", "k_ssim_gauss",
-                                             "k_ssim_ffmpeg", "k_orb64"};
+                                             "k_ssim_ffmpeg", "k_orb64", "farneback(pyramid)"};
     return (id >= 0 && id < VQA_K_COUNT) ? names[id] : "?";
 }
 

@@ -56,6 +56,31 @@ void launch_canny_finish(hipStream_t st, int n, vqa_frame_metrics *res);
 void launch_block_sad(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
                       int range, bool first_has_prev, vqa_frame_metrics *res);
 
+// k_farneback.hip
+struct fb_taps {       // one Gaussian blur kernel (getGaussianKernel, CV_32F), ksize <= 31
+    float k[32];
+    int ksize;
+};
+struct fb_poly {       // FarnebackPrepareGaussian(n = 5, sigma = 1.2)
+    float g[11], xg[11], xxg[11];
+    double ig11, ig03, ig33, ig55;
+};
+struct fb_resize_tabs { // cv2.resize INTER_LINEAR tables for float data (device pointers)
+    int32_t *xofs = nullptr, *yofs = nullptr;
+    float *xa = nullptr, *yb = nullptr;
+    int mode = 0;      // 1 = exact 2x decimation
+};
+void launch_fb_blur(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int planes, int h, int w,
+                    const fb_taps &T, float *tmp, float *out);
+void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, float *dst, int dh, int dw, int images,
+                      const fb_resize_tabs &T, float mul, bool apply_mul);
+void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out);
+void launch_fb_update(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *M);
+void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int w, float *flow);
+int fb_mag_blocks();
+void launch_fb_mag(hipStream_t st, const float *flow, int pairs, int h, int w, double *partials, bool first_valid,
+                   vqa_frame_metrics *res);
+
 // k_quality.hip
 int ssim_gauss_blocks(int h, int w);
 void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dist, int n, int64_t ref_frame_stride,

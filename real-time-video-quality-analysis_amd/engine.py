@@ -24,7 +24,7 @@ FRAME_DTYPE = np.dtype([
     ("edge_strong", np.uint32),
     ("edge_weak", np.uint32),
     ("has_prev", np.uint32),
-    ("hyst_steps", np.uint32), ("orb_keypoints", np.uint32), ("orb_response", np.uint32),
+    ("hyst_steps", np.uint32), ("orb_keypoints", np.uint32), ("orb_response", np.uint32), ("flow_mag_mean", np.float64),
 ], align=True)
 PLANE_DTYPE = np.dtype([("sse", np.uint64), ("ssim", np.float64)], align=True)
 assert FRAME_DTYPE.itemsize == C.sizeof(N.VqaFrameMetrics), (FRAME_DTYPE.itemsize, C.sizeof(N.VqaFrameMetrics))
@@ -155,7 +155,7 @@ class Engine:
         return self.lib.vqa_stream(self.ctx)
 
     # ---- complexity --------------------------------------------------------
-    def make_params(self, resize=None, canny=(100, 200), sad_range=7, dct_mode=N.DCT_AUTO):
+    def make_params(self, resize=None, canny=(100, 200), sad_range=7, dct_mode=N.DCT_AUTO, motion_mode=N.MOTION_SAD):
         p = N.VqaParams()
         self.lib.vqa_default_params(C.byref(p))
         if resize:
@@ -163,6 +163,7 @@ class Engine:
         p.canny_low, p.canny_high = int(canny[0]), int(canny[1])
         p.sad_range = int(sad_range)
         p.dct_mode = int(dct_mode)
+        p.motion_mode = int(motion_mode)
         return p
 
     @staticmethod

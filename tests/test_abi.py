@@ -59,7 +59,7 @@ def test_constants_match_header():
     """Mask bits, modes, status codes and kernel ids of the ctypes binding are the header's."""
     from rtvqa_amd import _native as N
     txt = open(os.path.join(REPO, "include", "vqa.h")).read()
-    for name, expr in re.findall(r"^#define\s+VQA_(M_\w+|DCT_\w+|SSIM_\w+|ABI_VERSION)\s+(\(?[0-9xA-Fa-fuU <]+\)?)", txt, flags=re.M):
+    for name, expr in re.findall(r"^#define\s+VQA_(M_\w+|DCT_\w+|SSIM_\w+|MOTION_\w+|ABI_VERSION)\s+(\(?[0-9xA-Fa-fuU <]+\)?)", txt, flags=re.M):
         val = eval(re.sub(r"(?<=[0-9a-fA-F])[uU]", "", expr))
         assert getattr(N, "VQA_ABI_VERSION" if name == "ABI_VERSION" else name) == val, name
     enum = re.search(r"enum vqa_kernel_id \{(.*?)\}", txt, flags=re.S).group(1)

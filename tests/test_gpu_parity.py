@@ -490,6 +490,45 @@ def test_orb_keypoint_count(engine, h, w):
     assert [(int(r["orb_keypoints"]), int(r["orb_response"])) for r in rec3] == want[:4]
 
 
+@pytest.mark.parametrize("h,w,kind", [(97, 131, "natural"), (64, 64, "natural"), (50, 300, "noise"), (33, 40, "natural"),
+                                      (135, 240, "natural"), (270, 480, "natural"), (16, 16, "noise"), (40, 900, "natural")])
+def test_farneback_motion_parity(engine, h, w, kind):
+    """VQA_MOTION_FARNEBACK (the reference's own motion metric, :340-343) against the oracle restatement.
+    The kernels evaluate the oracle's float/double expressions in its order with contraction off, so the
+    mean magnitude agrees far inside the 1e-4 bar; the batch also crosses a chunk of several pairs."""
+    from rtvqa_amd import _native as N
+    fr = _frames(kind, 4, h, w, seed=h + w)
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_MOTION, motion_mode=N.MOTION_FARNEBACK)
+    gray = [co.bgr2gray(f) for f in fr]
+    for i in range(3):
+        want = co.farneback(gray[i], gray[i + 1])
+        got = float(rec[i]["flow_mag_mean"])
+        assert abs(got - want) <= RTOL * want + 1e-7, (i, got, want)
+        assert int(rec[i]["sad_blocks"]) == 0  # the SAD kernel did not run
+    # no previous frame for the first one: 0.0, as the reference's None check (:324-325)
+    rec = engine.complexity(fr[1:3], mask=N.M_MOTION, motion_mode=N.MOTION_FARNEBACK)
+    assert float(rec[0]["flow_mag_mean"]) == 0.0 and int(rec[0]["has_prev"]) == 0
+    assert abs(float(rec[1]["flow_mag_mean"]) - co.farneback(gray[1], gray[2])) <= RTOL * co.farneback(gray[1], gray[2])
+
+
+def test_farneback_known_translation_1080p(engine):
+    """Full size: a smooth texture panned by (2, 1) pixels per frame -> mean |flow| = sqrt(5) within 1 %;
+    identical frames -> ~0; and the suite's other metrics are untouched by the motion mode."""
+    import scipy.ndimage as ndi
+    from rtvqa_amd import _native as N
+    a = ndi.gaussian_filter(_rng(77).integers(0, 256, (1080 + 16, 1920 + 16)).astype(np.float32), 2.5)
+    a = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+    fr = np.stack([np.repeat(a[8 + k:8 + k + 1080, 8 + 2 * k:8 + 2 * k + 1920, None], 3, axis=2) for k in range(3)] +
+                  [np.repeat(a[10:1090, 12:1932, None], 3, axis=2)])  # frame 3 == frame 2
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8, motion_mode=N.MOTION_FARNEBACK)
+    for i in range(2):
+        assert abs(float(rec[i]["flow_mag_mean"]) - 5 ** 0.5) < 0.01 * 5 ** 0.5
+    assert float(rec[2]["flow_mag_mean"]) < 1e-3
+    ref = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL & ~N.M_MOTION, dct_mode=N.DCT_BLOCK8)
+    for k in ("hist_gray", "edge_count", "dct_energy", "temporal_dct_l1", "orb_keypoints"):
+        assert (rec[k] == ref[k]).all(), k
+
+
 def test_region_of_interest_padded_rows(engine):
     """row_stride > 3w: a window inside larger frames, host and device resident, odd (unaligned) origins.
     The host window ends at the very last byte of its parent array, so any read past a row's 3w bytes

@@ -287,3 +287,51 @@ def test_orb64_count_window_and_nms():
         assert n == no.orb64_count(g) and n in (0, 1) and (r > 0) == (n == 1)
         seen.add(n)
     assert seen == {0, 1}
+
+
+# ---- Farneback dense flow (reference-true motion, :340-343) ------------------------------------
+def _smooth_texture(h, w, seed):
+    import scipy.ndimage as ndi
+    a = ndi.gaussian_filter(_rng(seed).integers(0, 256, (h, w)).astype(float), 2.0)
+    return ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+
+
+def test_farneback_recovers_translations():
+    big = _smooth_texture(300, 400, 50)
+    a = big[20:220, 30:330]
+    for dy, dx in ((0, 1), (1, 2), (3, -2), (0, 6)):
+        b = big[20 + dy:220 + dy, 30 + dx:330 + dx]   # b(y, x) = a(y + dy, x + dx): content moves by (-dx, -dy)
+        m, fl = co.farneback(a, b, want_flow=True)
+        assert abs(m - np.hypot(dx, dy)) < 0.01 * np.hypot(dx, dy) + 0.01
+        assert abs(np.median(fl[30:-30, 30:-30, 0]) + dx) < 0.01 and abs(np.median(fl[30:-30, 30:-30, 1]) + dy) < 0.01
+    # identical frames: zero flow except the last row / column, where OpenCV's warp has no neighbour to read
+    m, fl = co.farneback(a, a, want_flow=True)
+    assert m < 1e-3 and np.abs(fl[8:-8, 8:-8]).max() < 1e-3
+
+
+def test_farneback_c_and_numpy_restatements_agree():
+    """oracle/vqa_oracle.c (float / double as OpenCV) vs oracle/np_oracle.py (float64, scipy.ndimage)."""
+    from rtvqa_amd import synth
+    for h, w in ((97, 131), (64, 64), (50, 300), (33, 40), (135, 240)):   # 0..2 pyramid levels, ragged sizes
+        fr = synth.s_natural(2, h, w, seed=h)
+        g0, g1 = co.bgr2gray(fr[0]), co.bgr2gray(fr[1])
+        m, fl = co.farneback(g0, g1, want_flow=True)
+        m2, fl2 = no.farneback_mean_mag(g0, g1, want_flow=True)
+        assert abs(m - m2) <= 1e-5 * m2 and np.abs(fl - fl2).max() < 1e-3, (h, w)
+    n0, n1 = (_rng(s).integers(0, 256, (72, 88), dtype=np.uint8) for s in (51, 52))
+    assert abs(co.farneback(n0, n1) - no.farneback_mean_mag(n0, n1)) <= 1e-5 * no.farneback_mean_mag(n0, n1)
+
+
+def test_farneback_expansion_constants():
+    g, xg, xxg, ig = co.fb_prepare()
+    assert abs(g.sum() - 1) < 1e-6 and np.allclose(g, g[::-1]) and np.allclose(xg, -xg[::-1])
+    G = np.zeros((6, 6))
+    x = np.arange(-5, 6, dtype=np.float64)
+    gg = np.outer(g.astype(np.float64), g.astype(np.float64))
+    X, Y = np.meshgrid(x, x)
+    G[0, 0], G[1, 1], G[3, 3], G[5, 5] = gg.sum(), (gg * X * X).sum(), (gg * X ** 4).sum(), (gg * X * X * Y * Y).sum()
+    G[2, 2] = G[0, 3] = G[0, 4] = G[3, 0] = G[4, 0] = G[1, 1]
+    G[4, 4] = G[3, 3]
+    G[3, 4] = G[4, 3] = G[5, 5]
+    iG = np.linalg.inv(G)
+    assert np.allclose(ig, [iG[1, 1], iG[0, 3], iG[3, 3], iG[5, 5]], rtol=1e-12)
