@@ -107,6 +107,8 @@ def main():
                     help="synthetic stream: s_natural (default) or s_noise (max-entropy bins, worst case for Canny fan-out)")
     ap.add_argument("--dct-mode", default="block8", choices=["block8", "full"],
                     help="block8 (default, north_star's 8x8 DCT) or full (the reference's full-frame cv2.dct, on fp32 MFMA)")
+    ap.add_argument("--motion", default="sad", choices=["sad", "farneback"],
+                    help="motion metric of the full suite: sad (north_star's block-SAD, default) or farneback (the reference's own)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the rank logic)")
     args = ap.parse_args()
@@ -194,7 +196,8 @@ def main():
     ref_b, dist_b, prev0 = ref_all.slice(1, B + 1), dist_all.slice(1, B + 1), dist_all.frame(0)
 
     mask = N.M_ALL if full else (N.M_DCT | N.M_TEMPORAL_DCT)
-    params = eng.make_params(dct_mode=N.DCT_BLOCK8 if args.dct_mode == "block8" else N.DCT_FULL)
+    params = eng.make_params(dct_mode=N.DCT_BLOCK8 if args.dct_mode == "block8" else N.DCT_FULL,
+                             motion_mode=N.MOTION_FARNEBACK if args.motion == "farneback" else N.MOTION_SAD)
     planes = bgr_planes(h, w)
     if yuv:  # quality kernels read the planar streams; the complexity kernels still read the BGR frames
         planes = yuv420p_planes(h, w)
@@ -304,7 +307,7 @@ def main():
                     % (args.content, synth.GENERATOR_VERSION),
             "config": {"workload": wl["name"] if args.ssim_mode == "gauss" else
                        wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"), "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams, "collective": (("rccl" if args.backend == "nccl" else "gloo") + " scalar all-reduce") if world > 1 else "none",
-                       "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode, "parallelism": "1 stream/GPU x%d" % world},
+                       "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode, "motion": args.motion, "parallelism": "1 stream/GPU x%d" % world},
             "roofline": roof, "kernels": kernels,
         }
         if cpu_line is not None:

@@ -52,13 +52,16 @@ def process_orb_frame_for_parallel(frame):
     return co.orb64_count(gray_frame)[0]
 
 
-# complexity_metrics.py:313-343 — block-SAD substitute (spec: vqa_oracle.c vqo_block_sad)
-def process_frame_complexity(frame_pair, sad_range=7):
+# complexity_metrics.py:313-343 — block-SAD substitute (spec: vqa_oracle.c vqo_block_sad), or with
+# motion="farneback" the reference's own metric (vqo_farneback_mean_mag)
+def process_frame_complexity(frame_pair, sad_range=7, motion="sad"):
     frame, prev_frame = frame_pair
     if frame is None or prev_frame is None:
         return 0.0
     curr_gray = co.bgr2gray(frame)
     prev_gray = co.bgr2gray(prev_frame)
+    if motion == "farneback":
+        return np.float32(co.farneback(prev_gray, curr_gray))
     nb, _sad, hist = co.block_sad(prev_gray, curr_gray, sad_range)
     return np.float32(no.motion_mag_from_hist(hist, nb))
 
@@ -109,12 +112,12 @@ def calculate_temporal_dct(frames, resize_width, resize_height, frame_interval=1
 # complexity_metrics.py:246-310 (fps from constant-rate timestamps)
 def calculate_average_scene_complexity(frames, resize_width, resize_height, frame_interval=10, smoothing_factor=0.8,
                                        num_workers=None, batch_size=100, dct_mode="full", fps=30.0,
-                                       dispatcher=serial_map, return_series=False):
+                                       dispatcher=serial_map, return_series=False, motion="sad"):
     idx = selected_indices(len(frames), frame_interval)
     frame_pairs = [(frames[idx[j]], frames[idx[j - 1]]) for j in range(1, len(idx))]
     if num_workers is None:
         num_workers = multiprocessing.cpu_count() // 2
-    motion = dispatcher(frame_pairs, process_frame_complexity, num_workers, batch_size)
+    motion = dispatcher(frame_pairs, functools.partial(process_frame_complexity, motion=motion), num_workers, batch_size)
     sel = [p[0] for p in frame_pairs]
     kw = dict(resize_width=resize_width, resize_height=resize_height)
     dct = dispatcher(sel, functools.partial(process_dct_frame, dct_mode=dct_mode, **kw), num_workers, batch_size)

@@ -16,7 +16,8 @@ Differences that are deliberate:
     is out of scope; no codec exists in the target image);
   * the dispatcher does not fork (a HIP context does not survive fork): a batch of
     frames is one kernel launch instead of one pickled frame per pool task;
-  * motion is block-SAD, not Farneback (BASELINE.json north_star);
+  * motion is block-SAD by default (BASELINE.json north_star); set_motion_mode("farneback") or
+    VQA_MOTION=farneback selects the reference's own Farneback flow (SURVEY.md §8f N4);
 No metric is ever computed on the CPU here; without the HIP library this module
 raises on first use.
 """
@@ -156,7 +157,20 @@ def _color_entropy(counts_bgr):
 _SQRT_K = np.sqrt(np.arange(129, dtype=np.float64))
 
 
+_MOTION_MODES = {"sad": N.MOTION_SAD, "farneback": N.MOTION_FARNEBACK}
+_motion_mode = _MOTION_MODES[os.environ.get("VQA_MOTION", "sad")]
+
+
+def set_motion_mode(mode):
+    """What the motion slot of the 8-tuple / process_frame_complexity computes: "sad" (north_star's 16x16
+    block-SAD mean |mv|, the default) or "farneback" (cv2.calcOpticalFlowFarneback mean magnitude, :340-343)."""
+    global _motion_mode
+    _motion_mode = _MOTION_MODES[mode]
+
+
 def _motion_magnitude(rec):
+    if _motion_mode == N.MOTION_FARNEBACK:
+        return np.float32(rec["flow_mag_mean"])  # np.mean of a float32 array is a float32 (:343)
     nb = int(rec["sad_blocks"])
     if nb == 0:
         return np.float32(0.0)
@@ -218,12 +232,14 @@ def process_edge_frame(frame, resize_width, resize_height):
 
 
 def process_frame_complexity(frame_pair):
-    """complexity_metrics.py:313-343 — motion between (current, previous); block-SAD mean |mv|."""
+    """complexity_metrics.py:313-343 — motion between (current, previous): block-SAD mean |mv|, or the
+    Farneback mean flow magnitude after set_motion_mode("farneback")."""
     frame, prev_frame = frame_pair
     if frame is None or prev_frame is None:
         return 0.0
     eng = get_engine()
-    rec = eng.complexity(np.asarray(frame)[None], prev0=np.asarray(prev_frame), mask=N.M_MOTION)
+    rec = eng.complexity(np.asarray(frame)[None], prev0=np.asarray(prev_frame), mask=N.M_MOTION,
+                         motion_mode=_motion_mode)
     return _scalar("motion", rec[0])
 
 
@@ -302,13 +318,13 @@ def _motion_batch(eng, pairs):
         live == list(range(live[0], live[0] + len(live)))
     if chained:
         arr = np.stack([np.asarray(pairs[j][0]) for j in live])
-        rec = eng.complexity(arr, prev0=np.asarray(pairs[live[0]][1]), mask=N.M_MOTION)
+        rec = eng.complexity(arr, prev0=np.asarray(pairs[live[0]][1]), mask=N.M_MOTION, motion_mode=_motion_mode)
         for k, j in enumerate(live):
             out[j] = _scalar("motion", rec[k])
     else:
         # arbitrary pairs: interleave (prev, curr) and keep every second result
         arr = np.stack([np.asarray(pairs[j][s]) for j in live for s in (1, 0)])
-        rec = eng.complexity(arr, mask=N.M_MOTION)
+        rec = eng.complexity(arr, mask=N.M_MOTION, motion_mode=_motion_mode)
         for k, j in enumerate(live):
             out[j] = _scalar("motion", rec[2 * k + 1])
     return out
@@ -340,7 +356,7 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
         engs = [engine or get_engine()]
     else:
         engs = list(get_engine_pair())  # host clip, several batches: copy/compute ping-pong
-    params = engs[0].make_params(resize=(resize_width, resize_height), dct_mode=dct_mode)
+    params = engs[0].make_params(resize=(resize_width, resize_height), dct_mode=dct_mode, motion_mode=_motion_mode)
     sel = idx[1 + lo:1 + hi]
     prev_i = idx[lo]
     first_global = lo == 0

@@ -204,33 +204,55 @@ __global__ __launch_bounds__(256) void k_fb_update(const float *__restrict__ R, 
 }
 
 // ---- FarnebackUpdateFlow_Blur: 15x15 box sums of the products + 2x2 solve --------------------------
-// Tile BS_TY x BS_TX outputs per workgroup.  Stage 1: the tile's rows +-7 (clamped), each column's
-// horizontal 15-sum in double (taps in the oracle's order, columns clamped) -> LDS.  Stage 2: vertical
-// 15-sum of those (rows clamped), scale, solve.
+// Tile BS_TY x BS_TX outputs per workgroup.  The tile's products (+-7 halo, rows and columns clamped =
+// replicated border) are staged in LDS once; stage 1 slides a 15-wide window along every (row, channel)
+// in double, stage 2 slides a 15-high window down every (column, channel), stage 3 scales and solves.
+// Sums are carried in double as in OpenCV; the sliding order differs from the oracle's tap order only at
+// the 1e-16 level, far below what the regularised solve can amplify.
 constexpr int BS_TX = 32, BS_TY = 16, BS_M = 7;
+constexpr int BS_IW = BS_TX + 2 * BS_M, BS_IH = BS_TY + 2 * BS_M;
 
 // grid = (ceil(w/BS_TX), ceil(h/BS_TY), pairs), block = 256
 __global__ __launch_bounds__(256) void k_fb_blur_solve(const float *__restrict__ M, int h, int w, float *__restrict__ flow)
 {
-    __shared__ double hs[BS_TY + 2 * BS_M][BS_TX][5];
+    __shared__ float tile[BS_IH][BS_IW][5];   // 27.6 KB
+    __shared__ double hs[BS_IH][BS_TX][5];    // 38.4 KB: horizontal sums, then (in place) the window sums
     const int64_t P = (int64_t)h * w;
     const float *Mp = M + (int64_t)blockIdx.z * P * 5;
     const int x0 = blockIdx.x * BS_TX, y0 = blockIdx.y * BS_TY;
-    for (int i = threadIdx.x; i < (BS_TY + 2 * BS_M) * BS_TX; i += 256) {
-        const int ty = i / BS_TX, tx = i - ty * BS_TX;
-        const int yy = min(max(y0 + ty - BS_M, 0), h - 1);
-        const int x = x0 + tx;
-        double a[5] = {0, 0, 0, 0, 0};
-        if (x < w) {
-            for (int k = -BS_M; k <= BS_M; k++) {
-                const int xx = min(max(x + k, 0), w - 1);
-                const float *m = Mp + ((int64_t)yy * w + xx) * 5;
+    for (int i = threadIdx.x; i < BS_IH * BS_IW; i += 256) {
+        const int ty = i / BS_IW, tx = i - ty * BS_IW;
+        const int yy = min(max(y0 + ty - BS_M, 0), h - 1), xx = min(max(x0 + tx - BS_M, 0), w - 1);
+        const float *m = Mp + ((int64_t)yy * w + xx) * 5;
 #pragma unroll
-                for (int c = 0; c < 5; c++) a[c] += m[c];
-            }
+        for (int c = 0; c < 5; c++) tile[ty][tx][c] = m[c];
+    }
+    __syncthreads();
+    // stage 1: thread = (row, channel); hs[row][x][c] = sum of tile[row][x .. x+14][c]
+    for (int i = threadIdx.x; i < BS_IH * 5; i += 256) {
+        const int ty = i / 5, c = i - ty * 5;
+        double a = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * BS_M + 1; k++) a += tile[ty][k][c];
+        hs[ty][0][c] = a;
+        for (int x = 1; x < BS_TX; x++) {
+            a += (double)tile[ty][x + 2 * BS_M][c] - (double)tile[ty][x - 1][c];
+            hs[ty][x][c] = a;
         }
+    }
+    __syncthreads();
+    // stage 2: thread = (column, channel); the window sum of rows y .. y+14 overwrites hs[y]: rows are
+    // consumed top-down and hs[y] is read for the last time when output y is produced
+    for (int i = threadIdx.x; i < BS_TX * 5; i += 256) {
+        const int tx = i / 5, c = i - tx * 5;
+        double a = 0;
 #pragma unroll
-        for (int c = 0; c < 5; c++) hs[ty][tx][c] = a[c];
+        for (int k = 0; k < 2 * BS_M + 1; k++) a += hs[k][tx][c];
+        for (int y = 0; y < BS_TY; y++) {
+            const double top = hs[y][tx][c];
+            hs[y][tx][c] = a;
+            if (y + 1 < BS_TY) a += hs[y + 2 * BS_M + 1][tx][c] - top;
+        }
     }
     __syncthreads();
     const double scale = 1. / 225.;
@@ -238,14 +260,9 @@ __global__ __launch_bounds__(256) void k_fb_blur_solve(const float *__restrict__
         const int ty = i / BS_TX, tx = i - ty * BS_TX;
         const int x = x0 + tx, y = y0 + ty;
         if (x >= w || y >= h) continue;
-        double v[5] = {0, 0, 0, 0, 0};
-        // hs row t holds image row clamp(y0 + t - 7): the window rows y-7..y+7 are rows ty .. ty+14
-        for (int k = 0; k <= 2 * BS_M; k++) {
+        double v[5];
 #pragma unroll
-            for (int c = 0; c < 5; c++) v[c] += hs[ty + k][tx][c];
-        }
-#pragma unroll
-        for (int c = 0; c < 5; c++) v[c] = v[c] * scale;
+        for (int c = 0; c < 5; c++) v[c] = hs[ty][tx][c] * scale;
         const double idet = 1. / (v[0] * v[2] - v[1] * v[1] + 1e-3);
         float *f = flow + ((int64_t)blockIdx.z * P + (int64_t)y * w + x) * 2;
         f[0] = (float)((v[0] * v[4] - v[1] * v[3]) * idet);

@@ -229,3 +229,25 @@ def test_two_engines_from_two_threads():
             t.join()
     for k in range(2):
         assert all(g == want[k] for g in got[k]), k
+
+
+def test_farneback_motion_mode_through_the_reference_surface():
+    """set_motion_mode("farneback"): process_frame_complexity and slot 0 of the 8-tuple become the
+    reference's own Farneback metric (:340-343)."""
+    from rtvqa_amd import complexity_metrics as cm
+    clip = _clip(24, 120, 160, seed=14)
+    cm.set_motion_mode("farneback")
+    try:
+        f, p = clip[5], clip[4]
+        got = cm.process_frame_complexity((f, p))
+        assert isinstance(got, np.float32) and _close(got, pl.process_frame_complexity((f, p), motion="farneback"))
+        pairs = [(clip[i], clip[i - 1]) for i in range(1, 6)]
+        got = cm.process_in_batches(pairs, cm.process_frame_complexity, 2, batch_size=3)
+        want = [pl.process_frame_complexity(pr, motion="farneback") for pr in pairs]
+        assert all(_close(a, b) for a, b in zip(got, want))
+        t = cm.calculate_average_scene_complexity(clip, 64, 64, frame_interval=4, batch_size=3)
+        w_ = pl.calculate_average_scene_complexity(list(clip), 64, 64, frame_interval=4, motion="farneback")
+        assert _close(t[0], w_[0]) and all(_close(a, b, exact=k == 3) for k, (a, b) in enumerate(zip(t[1:], w_[1:]), 1))
+    finally:
+        cm.set_motion_mode("sad")
+    assert cm.process_frame_complexity((clip[5], clip[4])) == pl.process_frame_complexity((clip[5], clip[4]))
