@@ -9,9 +9,10 @@
 // is spelled out next to its CPU restatement, oracle/vqa_oracle.c vqo_farneback_mean_mag.
 //
 // Every kernel evaluates the same float / double expressions in the same order as that restatement, and
-// this translation unit is compiled with floating-point contraction OFF, so intermediate planes are
-// bit-identical to the oracle's: the 2x2 solve is ill-conditioned wherever the image is flat or has a
-// single orientation, and a fused multiply-add in the products would show up in the flow there.
+// this translation unit is compiled with floating-point contraction OFF, so the float planes (blurred
+// images, expansions, products) are bit-identical to the oracle's: the 2x2 solve is ill-conditioned wherever
+// the image is flat or has a single orientation, and a fused multiply-add in the products would show up
+// in the flow there.  (The double box sums differ from the oracle's tap order at the 1e-16 level only.)
 //
 // Structure per pyramid level (coarse to fine), for a chunk of frame pairs whose planes stay resident:
 //   k_fb_blur_h / k_fb_blur_v : float(gray) -> separable Gaussian, BORDER_REFLECT_101   (per plane, shared
