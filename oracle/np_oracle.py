@@ -288,7 +288,10 @@ def orb64_count(gray64, threshold=20):
 # ---------------------------------------------------------------------------
 # Farneback dense flow, vectorised in float64 with scipy.ndimage: an independent
 # restatement of oracle/vqa_oracle.c's vqo_farneback_mean_mag (same published
-# algorithm, different code shape, no float32 rounding) for cross-checking.
+# algorithm, different code shape, no float32 rounding) for cross-checking.  Valid for
+# frames of at least 10x10 pixels: below that OpenCV's unsigned border test
+# `(unsigned)(x - 5) >= (unsigned)(w - 10)` wraps and scales only some border pixels,
+# which the C restatement (and the GPU) reproduce literally and this one does not.
 # ---------------------------------------------------------------------------
 def _fb_resize(img, dh, dw):
     img = np.asarray(img, np.float64)
