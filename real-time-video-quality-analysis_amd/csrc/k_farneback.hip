@@ -36,12 +36,16 @@ __device__ __forceinline__ int fb_reflect101(int i, int n)
 }
 
 // ---- Gaussian blur, horizontal pass straight from the u8 gray plane -------------------------------
-// grid = (ceil(w/256), h, planes)
+// Only the columns in `cols` (all when null) are produced: at the coarse levels the bilinear resize that
+// follows samples 2 of every 4 or 8 columns and rows, and nothing else reads the blurred plane.
+// grid = (ceil(nc/256), h, planes)
 __global__ __launch_bounds__(256) void k_fb_blur_h(const uint8_t *__restrict__ gray, int pitch, int64_t plane_stride,
-                                                   int h, int w, fb_taps T, float *__restrict__ out)
+                                                   int h, int w, fb_taps T, const int32_t *__restrict__ cols, int nc,
+                                                   float *__restrict__ out)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (i >= nc) return;
+    const int x = cols ? cols[i] : i;
     const uint8_t *row = gray + (int64_t)blockIdx.z * plane_stride + (int64_t)y * pitch;
     const int r = T.ksize >> 1;
     float a = (float)row[x] * T.k[r];
@@ -50,11 +54,14 @@ __global__ __launch_bounds__(256) void k_fb_blur_h(const uint8_t *__restrict__ g
     out[((int64_t)blockIdx.z * h + y) * w + x] = a;
 }
 
+// grid = (ceil(nc/256), nr, planes)
 __global__ __launch_bounds__(256) void k_fb_blur_v(const float *__restrict__ in, int h, int w, fb_taps T,
-                                                   float *__restrict__ out)
+                                                   const int32_t *__restrict__ cols, int nc,
+                                                   const int32_t *__restrict__ rows, float *__restrict__ out)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc) return;
+    const int x = cols ? cols[i] : i, y = rows ? rows[blockIdx.y] : (int)blockIdx.y;
     const float *img = in + (int64_t)blockIdx.z * h * w;
     const int r = T.ksize >> 1;
     float a = img[(int64_t)y * w + x] * T.k[r];
@@ -213,15 +220,16 @@ __global__ __launch_bounds__(256) void k_fb_update(const float *__restrict__ R, 
 constexpr int BS_TX = 32, BS_TY = 16, BS_M = 7;
 constexpr int BS_IW = BS_TX + 2 * BS_M, BS_IH = BS_TY + 2 * BS_M;
 
-// grid = (ceil(w/BS_TX), ceil(h/BS_TY), pairs), block = 256
-__global__ __launch_bounds__(256) void k_fb_blur_solve(const float *__restrict__ M, int h, int w, float *__restrict__ flow)
+constexpr int BS_NT = 1024; // 16 waves share one 66 KB tile: the global->LDS fill and the solve dominate, both want threads
+// grid = (ceil(w/BS_TX), ceil(h/BS_TY), pairs), block = BS_NT
+__global__ __launch_bounds__(BS_NT) void k_fb_blur_solve(const float *__restrict__ M, int h, int w, float *__restrict__ flow)
 {
     __shared__ float tile[BS_IH][BS_IW][5];   // 27.6 KB
     __shared__ double hs[BS_IH][BS_TX][5];    // 38.4 KB: horizontal sums, then (in place) the window sums
     const int64_t P = (int64_t)h * w;
     const float *Mp = M + (int64_t)blockIdx.z * P * 5;
     const int x0 = blockIdx.x * BS_TX, y0 = blockIdx.y * BS_TY;
-    for (int i = threadIdx.x; i < BS_IH * BS_IW; i += 256) {
+    for (int i = threadIdx.x; i < BS_IH * BS_IW; i += BS_NT) {
         const int ty = i / BS_IW, tx = i - ty * BS_IW;
         const int yy = min(max(y0 + ty - BS_M, 0), h - 1), xx = min(max(x0 + tx - BS_M, 0), w - 1);
         const float *m = Mp + ((int64_t)yy * w + xx) * 5;
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void k_fb_blur_solve(const float *__restrict__
     }
     __syncthreads();
     // stage 1: thread = (row, channel); hs[row][x][c] = sum of tile[row][x .. x+14][c]
-    for (int i = threadIdx.x; i < BS_IH * 5; i += 256) {
+    for (int i = threadIdx.x; i < BS_IH * 5; i += BS_NT) {
         const int ty = i / 5, c = i - ty * 5;
         double a = 0;
 #pragma unroll
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) void k_fb_blur_solve(const float *__restrict__
     __syncthreads();
     // stage 2: thread = (column, channel); the window sum of rows y .. y+14 overwrites hs[y]: rows are
     // consumed top-down and hs[y] is read for the last time when output y is produced
-    for (int i = threadIdx.x; i < BS_TX * 5; i += 256) {
+    for (int i = threadIdx.x; i < BS_TX * 5; i += BS_NT) {
         const int tx = i / 5, c = i - tx * 5;
         double a = 0;
 #pragma unroll
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256) void k_fb_blur_solve(const float *__restrict__
     }
     __syncthreads();
     const double scale = 1. / 225.;
-    for (int i = threadIdx.x; i < BS_TY * BS_TX; i += 256) {
+    for (int i = threadIdx.x; i < BS_TY * BS_TX; i += BS_NT) {
         const int ty = i / BS_TX, tx = i - ty * BS_TX;
         const int x = x0 + tx, y = y0 + ty;
         if (x >= w || y >= h) continue;
@@ -298,11 +306,13 @@ __global__ void k_fb_mag_finalize(const double *__restrict__ partials, int pairs
 
 // ---- launchers -------------------------------------------------------------------------------------
 void launch_fb_blur(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int planes, int h, int w,
-                    const fb_taps &T, float *tmp, float *out)
+                    const fb_taps &T, const int32_t *cols, int nc, const int32_t *rows, int nr, float *tmp, float *out)
 {
-    dim3 grid((w + 255) / 256, h, planes);
-    hipLaunchKernelGGL(k_fb_blur_h, grid, dim3(256), 0, st, gray, pitch, plane_stride, h, w, T, tmp);
-    hipLaunchKernelGGL(k_fb_blur_v, grid, dim3(256), 0, st, tmp, h, w, T, out);
+    if (!cols) nc = w;
+    if (!rows) nr = h;
+    hipLaunchKernelGGL(k_fb_blur_h, dim3((nc + 255) / 256, h, planes), dim3(256), 0, st, gray, pitch, plane_stride, h, w, T,
+                       cols, nc, tmp);
+    hipLaunchKernelGGL(k_fb_blur_v, dim3((nc + 255) / 256, nr, planes), dim3(256), 0, st, tmp, h, w, T, cols, nc, rows, out);
 }
 
 void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, float *dst, int dh, int dw, int images,
@@ -332,7 +342,7 @@ void launch_fb_update(hipStream_t st, const float *R, const float *flow, int pai
 void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int w, float *flow)
 {
     dim3 grid((w + BS_TX - 1) / BS_TX, (h + BS_TY - 1) / BS_TY, pairs);
-    hipLaunchKernelGGL(k_fb_blur_solve, grid, dim3(256), 0, st, M, h, w, flow);
+    hipLaunchKernelGGL(k_fb_blur_solve, grid, dim3(BS_NT), 0, st, M, h, w, flow);
 }
 
 int fb_mag_blocks() { return FB_MAG_BLOCKS; }

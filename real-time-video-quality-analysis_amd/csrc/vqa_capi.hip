@@ -290,6 +290,24 @@ static int get_fb_tabs(vqa_ctx *c, int sh, int sw, int dh, int dw, fb_resize_tab
     HIPCHK(c, hipMemcpy(t.xa, xa.data(), sizeof(float) * 2 * dw, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(t.yofs, yo.data(), sizeof(int32_t) * dh, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(t.yb, yb.data(), sizeof(float) * 2 * dh, hipMemcpyHostToDevice));
+    if (t.mode == 0 && (dw < sw || dh < sh)) {
+        // what the bilinear taps read: columns xofs, min(xofs + 1, sw - 1); rows clamp(yofs), clamp(yofs + 1)
+        std::vector<int32_t> cs, rs;
+        std::vector<char> cm(sw, 0), rm(sh, 0);
+        for (int d = 0; d < dw; d++) { cm[xo[d]] = 1; cm[xo[d] + 1 < sw ? xo[d] + 1 : sw - 1] = 1; }
+        for (int d = 0; d < dh; d++) {
+            const int y0 = yo[d] < 0 ? 0 : (yo[d] > sh - 1 ? sh - 1 : yo[d]);
+            const int y1 = yo[d] + 1 < 0 ? 0 : (yo[d] + 1 > sh - 1 ? sh - 1 : yo[d] + 1);
+            rm[y0] = 1; rm[y1] = 1;
+        }
+        for (int x = 0; x < sw; x++) if (cm[x]) cs.push_back(x);
+        for (int y = 0; y < sh; y++) if (rm[y]) rs.push_back(y);
+        t.nc = (int)cs.size(); t.nr = (int)rs.size();
+        HIPCHK(c, hipMalloc((void **)&t.cols, sizeof(int32_t) * t.nc));
+        HIPCHK(c, hipMalloc((void **)&t.rows, sizeof(int32_t) * t.nr));
+        HIPCHK(c, hipMemcpy(t.cols, cs.data(), sizeof(int32_t) * t.nc, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(t.rows, rs.data(), sizeof(int32_t) * t.nr, hipMemcpyHostToDevice));
+    }
     c->fb_tabs[key] = t;
     out = t;
     return VQA_OK;
@@ -346,14 +364,18 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
                 if ((rc = get_fb_tabs(c, ph, pw, lh, lw, T))) return rc;
                 launch_fb_resize(st, prev_flow, ph, pw, 2, flow, lh, lw, pairs, T, (float)(1. / pyr_scale), true);
             }
-            // every plane once: blur at full resolution, resize to the level, polynomial expansion
-            launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, fb_gauss_taps(smooth_sz, sigma), tmp, blur);
+            // every plane once: blur (only where the resize will sample), resize to the level, polynomial expansion
             const float *level_img = blur;
             if (lw != w || lh != h) {
                 fb_resize_tabs T;
                 if ((rc = get_fb_tabs(c, h, w, lh, lw, T))) return rc;
+                launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, fb_gauss_taps(smooth_sz, sigma), T.cols, T.nc, T.rows,
+                               T.nr, tmp, blur);
                 launch_fb_resize(st, blur, h, w, 1, img, lh, lw, planes, T, 1.f, false);
                 level_img = img;
+            } else {
+                launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, fb_gauss_taps(smooth_sz, sigma), nullptr, 0, nullptr, 0,
+                               tmp, blur);
             }
             launch_fb_polyexp(st, level_img, planes, lh, lw, PC, R);
             launch_fb_update(st, R, flow, pairs, lh, lw, M);
@@ -440,6 +462,8 @@ int vqa_destroy(vqa_ctx *c)
     }
     for (auto &kv : c->fb_tabs) {
         (void)hipFree(kv.second.xofs); (void)hipFree(kv.second.xa); (void)hipFree(kv.second.yofs); (void)hipFree(kv.second.yb);
+        if (kv.second.cols) (void)hipFree(kv.second.cols);
+        if (kv.second.rows) (void)hipFree(kv.second.rows);
     }
     for (auto &kv : c->dct_mats) (void)hipFree(kv.second);
     for (auto &t : c->ev_open) { (void)hipEventDestroy(std::get<1>(t)); (void)hipEventDestroy(std::get<2>(t)); }

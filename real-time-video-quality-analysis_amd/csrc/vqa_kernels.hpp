@@ -69,9 +69,13 @@ struct fb_resize_tabs { // cv2.resize INTER_LINEAR tables for float data (device
     int32_t *xofs = nullptr, *yofs = nullptr;
     float *xa = nullptr, *yb = nullptr;
     int mode = 0;      // 1 = exact 2x decimation
+    // the source columns / rows a bilinear downscale actually samples (sorted, unique); null = all of them
+    int32_t *cols = nullptr, *rows = nullptr;
+    int nc = 0, nr = 0;
 };
+// blurred values are produced only at the columns / rows listed (all when null): the level's resize reads nothing else
 void launch_fb_blur(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int planes, int h, int w,
-                    const fb_taps &T, float *tmp, float *out);
+                    const fb_taps &T, const int32_t *cols, int nc, const int32_t *rows, int nr, float *tmp, float *out);
 void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, float *dst, int dh, int dw, int images,
                       const fb_resize_tabs &T, float mul, bool apply_mul);
 void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out);
