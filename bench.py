@@ -50,7 +50,7 @@ def _cpu_item(item):
     from oracle import c_oracle as co
     from oracle import pipeline as pl
     from rtvqa_amd.engine import bgr_planes
-    ref, dist, prev, full = item
+    ref, dist, prev, full, motion = item
     h, w = dist.shape[:2]
     out = []
     sse, ssim = pl.frame_quality(ref, dist, bgr_planes(h, w), "gauss")
@@ -59,14 +59,14 @@ def _cpu_item(item):
     out += list(co.dct8x8(gp, g)[:2])
     if full:
         out.append(co.canny(g, 100, 200)[0])
-        out += list(co.block_sad(gp, g, 7)[:2])
+        out += [co.farneback(gp, g)] if motion == "farneback" else list(co.block_sad(gp, g, 7)[:2])
         out.append(int(co.hist_u8(g).sum()))
         out += [int(co.hist_u8(dist, offset=c, step=3).sum()) for c in range(3)]
         out.append(pl.process_orb_frame_for_parallel(dist))
     return out
 
 
-def cpu_baseline(ref, dist, full, sample):
+def cpu_baseline(ref, dist, full, sample, motion="sad"):
     from concurrent.futures import ProcessPoolExecutor
     from oracle import c_oracle as co
     co.build()
@@ -76,7 +76,7 @@ def cpu_baseline(ref, dist, full, sample):
         cores = os.cpu_count() or 1
     cores = min(cores, int(os.environ.get("VQA_CPU_CORES", "16")))  # a 1-GPU box's share is 16 cores
     workers = max(1, cores // 2)  # complexity_metrics.py:264-265
-    items = [(ref[i], dist[i], dist[i - 1] if i else dist[0], full) for i in range(sample)]
+    items = [(ref[i], dist[i], dist[i - 1] if i else dist[0], full, motion) for i in range(sample)]
     t0 = time.perf_counter()
     results = []
     with ProcessPoolExecutor(max_workers=workers) as ex:
@@ -129,7 +129,7 @@ def main():
         from rtvqa_amd import synth as _synth
         sample = args.cpu_sample if args.cpu_sample > 0 else 32
         r = _synth.s_natural(sample, h, w, seed=1234, stream_id=0, t0=0)
-        cpu_line = cpu_baseline(r, _synth.distort(r, t0=0), full, sample)
+        cpu_line = cpu_baseline(r, _synth.distort(r, t0=0), full, sample, args.motion)
         del r
 
     import torch
