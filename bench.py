@@ -262,6 +262,9 @@ def main():
             "k_dct8": 2 * P * B, "k_bgr2gray_hist": 4 * P * (B + 1),
             "k_canny_nms": P * B + P * B // 4,  # reads gray, writes two bit-planes (P/8 each)
             "k_block_sad": 2 * P * B,
+            # Farneback, per level-0 pixel and pair, every kernel reading its inputs and writing its outputs once:
+            # expansion 24 B + 3 x (product rebuild 68 B + box/solve 28 B) = 312 B, x 4/3 for the pyramid, + ~25 B of blur
+            "farneback(pyramid)": 440 * P * B,
         }
         kernels = {}
         for name, (ms, cnt) in prof.items():
