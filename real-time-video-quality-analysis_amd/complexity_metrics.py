@@ -452,8 +452,8 @@ def calculate_average_scene_complexity_sharded(video_path, resize_width, resize_
             part[-1] = float(np.dot(ct, np.asarray(s["temporal"], np.float64)))
     backend = td.get_backend(group)
     t = torch.from_numpy(part)
-    if backend == "nccl":
-        t = t.cuda()
+    if backend == "nccl":  # RCCL reduces device tensors: use this rank's engine device, not torch's default
+        t = t.to("cuda:%d" % get_engine().device)
     td.all_reduce(t, op=td.ReduceOp.SUM, group=group)
     tot = t.cpu().numpy()
     nan = float("nan")
