@@ -144,13 +144,17 @@ def test_device_resident_clip_with_interval():
     assert _close(a[1], want[1]) and a[3] == want[3] and _close(a[6], want[6]) and a[0] == want[0]
 
 
-def _sharded_gpu_worker(rank, world, port, clip, interval, resize, out_path):
+def _sharded_gpu_worker(rank, world, port, clip, interval, resize, out_path, backend="gloo"):
     import os
+    import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["VQA_DEVICE"] = "0"  # a 1-GPU box: every rank on device 0 (on a node: LOCAL_RANK)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from rtvqa_amd import complexity_metrics as cm
     got = cm.calculate_average_scene_complexity_sharded(clip, resize[0], resize[1], frame_interval=interval, batch_size=4)
     np.save(out_path % rank, np.array(got, np.float64))
@@ -158,8 +162,9 @@ def _sharded_gpu_worker(rank, world, port, clip, interval, resize, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,interval,resize,world", [(64, 5, (64, 64), 2), (23, 2, (80, 60), 3)])
-def test_sharded_stream_on_gpu_equals_single_process(tmp_path, n, interval, resize, world):
+@pytest.mark.parametrize("n,interval,resize,world,backend", [(64, 5, (64, 64), 2, "gloo"), (23, 2, (80, 60), 3, "gloo"),
+                                                            (23, 2, (80, 60), 1, "nccl")])
+def test_sharded_stream_on_gpu_equals_single_process(tmp_path, n, interval, resize, world, backend):
     """one long stream split over ranks (contiguous ranges + 1-frame halo), every rank running
     the real HIP path, pooled by one scalar all-reduce — equals the single-process 8-tuple."""
     import socket
@@ -171,7 +176,8 @@ def test_sharded_stream_on_gpu_equals_single_process(tmp_path, n, interval, resi
         sck.bind(("127.0.0.1", 0))
         port = sck.getsockname()[1]
     out = str(tmp_path / "g%d.npy")
-    mp.spawn(_sharded_gpu_worker, args=(world, port, clip, interval, resize, out), nprocs=world, join=True)
+    # (RCCL refuses two ranks on one device, so the device-tensor reduction is exercised with one rank here)
+    mp.spawn(_sharded_gpu_worker, args=(world, port, clip, interval, resize, out, backend), nprocs=world, join=True)
     for r in range(world):
         got = np.load(out % r)
         for k in range(8):
