@@ -110,7 +110,7 @@ typedef struct vqa_frame_metrics {
     uint32_t edge_strong;        /* pixels above `high` that survive NMS                    */
     uint32_t edge_weak;          /* NMS survivors in (low, high]                            */
     uint32_t has_prev;           /* 1 if a previous frame was available                     */
-    uint32_t hyst_steps;         /* diagnostics: relaxation steps summed over this frame's tiles       */
+    uint32_t hyst_steps;         /* diagnostics only (scheduling-dependent): relaxation steps summed over tiles */
     uint32_t orb_keypoints;      /* len(ORB_create().detectAndCompute(gray64)[0])  (:385-389)  */
     uint32_t orb_response;       /* FAST score of that keypoint, 0 when there is none       */
     double   flow_mag_mean;      /* VQA_MOTION_FARNEBACK: np.mean(|flow|) (:342-343); else 0 */

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -53,7 +54,7 @@ struct vqa_ctx {
 
     // pending work
     int pend_c = 0, pend_q = 0;
-    bool pend_c_prev0 = false;
+    bool pend_c_prev0 = false, pend_c_tail_only = false;
     // geometry of the last complexity batch (debug reads)
     int last_n = 0, last_h = 0, last_w = 0, last_ph = 0, last_pw = 0, last_pp = 0, last_gp = 0;
     bool last_resized = false, last_has_full = false, last_has_state = false, last_has_planes = false;
@@ -745,7 +746,16 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     }
 
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->res_host, c->res_dev.p, sizeof(vqa_frame_metrics) * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (want_gh || want_ch) {
+        HIPCHK(c, hipMemcpyAsync(c->res_host, c->res_dev.p, sizeof(vqa_frame_metrics) * (size_t)n, hipMemcpyDeviceToHost, st));
+        c->pend_c_tail_only = false;
+    } else {
+        // no histogram was asked for: bring back only the 0.6 KB of scalars behind the 4 KB of bins of each record
+        const size_t off = offsetof(vqa_frame_metrics, sum_gray2), tail = sizeof(vqa_frame_metrics) - off;
+        HIPCHK(c, hipMemcpy2DAsync((uint8_t *)c->res_host + off, sizeof(vqa_frame_metrics), (uint8_t *)c->res_dev.p + off,
+                                   sizeof(vqa_frame_metrics), tail, (size_t)n, hipMemcpyDeviceToHost, st));
+        c->pend_c_tail_only = true;
+    }
     c->pend_c = n;
     c->pend_c_prev0 = has_prev0;
     c->last_n = n; c->last_h = h; c->last_w = w; c->last_ph = ph; c->last_pw = pw; c->last_pp = pp; c->last_gp = gp;
@@ -760,7 +770,10 @@ int vqa_complexity_wait(vqa_ctx *c, vqa_frame_metrics *out, int n)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     memcpy(out, c->res_host, sizeof(vqa_frame_metrics) * (size_t)n);
-    for (int i = 0; i < n; i++) out[i].has_prev = (i > 0 || c->pend_c_prev0) ? 1u : 0u;
+    for (int i = 0; i < n; i++) {
+        if (c->pend_c_tail_only) memset(&out[i], 0, offsetof(vqa_frame_metrics, sum_gray2)); // bins were not computed
+        out[i].has_prev = (i > 0 || c->pend_c_prev0) ? 1u : 0u;
+    }
     c->pend_c = 0;
     return VQA_OK;
 }

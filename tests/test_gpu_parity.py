@@ -28,6 +28,13 @@ def _frames(kind, n, h, w, seed=0):
     raise KeyError(kind)
 
 
+def _stable(rec):
+    """Bytes of a result batch without the one field that is diagnostic and scheduling-dependent."""
+    rec = rec.copy()
+    rec["hyst_steps"] = 0
+    return rec.tobytes()
+
+
 def _rel(a, b):
     return abs(a - b) / max(abs(b), 1e-30)
 
@@ -545,7 +552,7 @@ def test_region_of_interest_padded_rows(engine):
         droi = dbig.roi(y0, y1, x0, x1)
         got_d = engine.complexity(droi.slice(1, 4), prev0=droi.frame(0), mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
         for got in (got_h, got_d):
-            assert got.tobytes() == want.tobytes(), (y0, y1, x0, x1)
+            assert _stable(got) == _stable(want), (y0, y1, x0, x1)
         g = co.bgr2gray(np.ascontiguousarray(sub[1]))
         assert (want[0]["hist_gray"] == co.hist_u8(g)).all()
         assert int(want[0]["edge_count"]) == co.canny(g, 100, 200)[0]
@@ -553,7 +560,7 @@ def test_region_of_interest_padded_rows(engine):
         want = engine.complexity(np.ascontiguousarray(sub[1:]), mask=N.M_GRAY_HIST | N.M_COLOR_HIST | N.M_DCT, resize=(40, 24))
         got_d = engine.complexity(droi.slice(1, 4), mask=N.M_GRAY_HIST | N.M_COLOR_HIST | N.M_DCT, resize=(40, 24))
         got_h = engine.complexity(sub[1:], mask=N.M_GRAY_HIST | N.M_COLOR_HIST | N.M_DCT, resize=(40, 24))
-        assert got_d.tobytes() == want.tobytes() and got_h.tobytes() == want.tobytes()
+        assert _stable(got_d) == _stable(want) and _stable(got_h) == _stable(want)
 
 
 def test_argument_errors(engine):
