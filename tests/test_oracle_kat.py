@@ -335,3 +335,23 @@ def test_farneback_expansion_constants():
     G[3, 4] = G[4, 3] = G[5, 5]
     iG = np.linalg.inv(G)
     assert np.allclose(ig, [iG[1, 1], iG[0, 3], iG[3, 3], iG[5, 5]], rtol=1e-12)
+
+
+# ---- regression pins of the restatement itself ----------------------------------------------
+def test_oracle_regression_pins():
+    """tests/golden/oracle_pins.json freezes the oracle's own outputs on seeded frames (oracle/gen_pins.py).
+    Not reference outputs — the reference cannot run here — but an accidental edit of the restatement shows."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import gen_pins
+    pins = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_pins.json")))["cases"]
+    now = gen_pins.cases()
+    assert [c["name"] for c in now] == [c["name"] for c in pins]
+    for a, b in zip(now, pins):
+        for k, v in b.items():
+            if isinstance(v, float):
+                assert abs(a[k] - v) <= 1e-9 * abs(v) + 1e-12, (b["name"], k, a[k], v)
+            else:
+                assert a[k] == v, (b["name"], k, a[k], v)
