@@ -29,10 +29,9 @@ def _frames(kind, n, h, w, seed=0):
 
 
 def _stable(rec):
-    """Bytes of a result batch without the one field that is diagnostic and scheduling-dependent."""
-    rec = rec.copy()
-    rec["hyst_steps"] = 0
-    return rec.tobytes()
+    """A result batch as comparable values: every field except the diagnostic, scheduling-dependent
+    hyst_steps (field by field: the record has alignment padding that NumPy copies do not preserve)."""
+    return tuple(rec[f].tobytes() for f in rec.dtype.names if f != "hyst_steps")
 
 
 def _rel(a, b):
