@@ -536,6 +536,31 @@ def test_farneback_known_translation_1080p(engine):
         assert (rec[k] == ref[k]).all(), k
 
 
+def test_many_small_frames_one_batch(engine):
+    """Thousands of frames in one submit (frames ride in gridDim.y; per-frame lists, counters, partials)."""
+    from rtvqa_amd import _native as N
+    n, h, w = 3000, 24, 40
+    fr = _rng(8).integers(0, 256, (n + 1, h, w, 3), dtype=np.uint8)
+    fr[::7, 8:16, 10:30] = 255
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8, canny=(30, 90))
+    for i in list(range(0, n, 211)) + [n - 1]:
+        g, gp = co.bgr2gray(fr[i + 1]), co.bgr2gray(fr[i])
+        assert (rec[i]["hist_gray"] == co.hist_u8(g)).all()
+        assert int(rec[i]["edge_count"]) == co.canny(g, 30, 90)[0]
+        nb, sad, hist = co.block_sad(gp, g, 7)
+        assert (int(rec[i]["sad_sum"]), int(rec[i]["sad_blocks"])) == (sad, nb) and (rec[i]["mv_d2_hist"] == hist).all()
+        e, l1, _ = co.dct8x8(gp, g)
+        assert _rel(rec[i]["dct_energy"], e) < RTOL and _rel(rec[i]["temporal_dct_l1"], l1) < RTOL
+        assert int(rec[i]["orb_keypoints"]) == co.orb64_count(co.bgr2gray(co.resize_linear(fr[i + 1], 64, 64)))[0]
+    from rtvqa_amd.engine import gray_planes
+    q = engine.quality(fr[:-1, ..., 1], fr[1:, ..., 1], gray_planes(h, w), N.SSIM_GAUSS)
+    for i in (0, 1499, n - 1):
+        a, b = np.ascontiguousarray(fr[i, ..., 1]), np.ascontiguousarray(fr[i + 1, ..., 1])
+        assert int(q[i, 0]["sse"]) == co.sse_plane(a, b) and _rel(q[i, 0]["ssim"], co.ssim_gauss(a, b)) < RTOL
+    with pytest.raises(N.VqaError):
+        engine.complexity(np.zeros((65536, 8, 8, 3), np.uint8), mask=N.M_GRAY_HIST)  # documented limit
+
+
 def test_region_of_interest_padded_rows(engine):
     """row_stride > 3w: a window inside larger frames, host and device resident, odd (unaligned) origins.
     The host window ends at the very last byte of its parent array, so any read past a row's 3w bytes
