@@ -18,7 +18,7 @@
 //   k_fb_blur_h / k_fb_blur_v : float(gray) -> separable Gaussian, BORDER_REFLECT_101   (per plane, shared
 //   k_fb_resize               : INTER_LINEAR float resize (2x2 mean when exactly halving)  by both pairs
 //   k_fb_polyexp              : 11x11 polynomial expansion -> 5 coefficients per pixel      it belongs to)
-//   k_fb_resize (x2)          : flow of the coarser level, upsampled and doubled
+//   (the coarser level's flow is upsampled and doubled inside the level's first k_fb_update)
 //   k_fb_update               : bilinear warp of the second expansion by the flow -> 5 products per pixel
 //   k_fb_blur_solve           : 15x15 box sums (double, replicated border) + regularised 2x2 solve -> flow
 // and k_fb_mag for the mean magnitude.  All of it is stencil work on fp32 planes: HBM / LDS / VALU, no MFMA.
@@ -163,8 +163,15 @@ __global__ __launch_bounds__(256) void k_fb_polyexp(const float *__restrict__ in
 
 // ---- FarnebackUpdateMatrices: pair p uses expansions of planes p and p + 1 -------------------------
 // grid = (ceil(w/256), h, pairs)
+// SRC: where the flow comes from.  0 = the level's flow field; 1 = the coarser level's flow, resized
+// (INTER_LINEAR, the k_fb_resize<2> arithmetic) and doubled on the fly — the first rebuild of a level is its
+// only reader, so the upsampled field is never written; 2 = zero (coarsest level).
+template <int SRC>
 __global__ __launch_bounds__(256) void k_fb_update(const float *__restrict__ R, const float *__restrict__ flow, int h,
-                                                   int w, float *__restrict__ M)
+                                                   int w, float *__restrict__ M, int ch, int cw,
+                                                   const int32_t *__restrict__ xofs, const float *__restrict__ xa,
+                                                   const int32_t *__restrict__ yofs, const float *__restrict__ yb,
+                                                   float mul)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
@@ -172,7 +179,25 @@ __global__ __launch_bounds__(256) void k_fb_update(const float *__restrict__ R, 
     const float *R0 = R + (int64_t)blockIdx.z * P * 5, *R1 = R0 + P * 5;
     const int64_t pix = (int64_t)blockIdx.z * P + (int64_t)y * w + x;
     const float *r0 = R0 + ((int64_t)y * w + x) * 5;
-    const float dx = flow[pix * 2], dy = flow[pix * 2 + 1];
+    float dx = 0.f, dy = 0.f;
+    if (SRC == 0) {
+        dx = flow[pix * 2];
+        dy = flow[pix * 2 + 1];
+    } else if (SRC == 1) {
+        const float *s = flow + (int64_t)blockIdx.z * ch * cw * 2;
+        const int x0 = xofs[x], x1c = min(x0 + 1, cw - 1);
+        const int y0 = min(max(yofs[y], 0), ch - 1), y1c = min(max(yofs[y] + 1, 0), ch - 1);
+        const float a0 = xa[2 * x], a1 = xa[2 * x + 1], b0 = yb[2 * y], b1 = yb[2 * y + 1];
+        float v[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float q0 = s[((int64_t)y0 * cw + x0) * 2 + c] * a0 + s[((int64_t)y0 * cw + x1c) * 2 + c] * a1;
+            const float q1 = s[((int64_t)y1c * cw + x0) * 2 + c] * a0 + s[((int64_t)y1c * cw + x1c) * 2 + c] * a1;
+            v[c] = (q0 * b0 + q1 * b1) * mul;
+        }
+        dx = v[0];
+        dy = v[1];
+    }
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     float r2, r3, r4, r5, r6;
@@ -349,7 +374,19 @@ void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w
 void launch_fb_update(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *M)
 {
     dim3 grid((w + 255) / 256, h, pairs);
-    hipLaunchKernelGGL(k_fb_update, grid, dim3(256), 0, st, R, flow, h, w, M);
+    hipLaunchKernelGGL(k_fb_update<0>, grid, dim3(256), 0, st, R, flow, h, w, M, 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f);
+}
+
+// first rebuild of a level: coarse == nullptr -> zero flow, else the coarser level's flow upsampled in flight
+void launch_fb_update_first(hipStream_t st, const float *R, const float *coarse, int ch, int cw, const fb_resize_tabs &T,
+                            float mul, int pairs, int h, int w, float *M)
+{
+    dim3 grid((w + 255) / 256, h, pairs);
+    if (!coarse)
+        hipLaunchKernelGGL(k_fb_update<2>, grid, dim3(256), 0, st, R, nullptr, h, w, M, 0, 0, nullptr, nullptr, nullptr,
+                           nullptr, 0.f);
+    else
+        hipLaunchKernelGGL(k_fb_update<1>, grid, dim3(256), 0, st, R, coarse, h, w, M, ch, cw, T.xofs, T.xa, T.yofs, T.yb, mul);
 }
 
 void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int w, float *flow)

@@ -357,14 +357,12 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
             int smooth_sz = (int)std::lrint(sigma * 5) | 1;
             if (smooth_sz < 3) smooth_sz = 3;
             const int lw = (int)std::lrint(w * scale), lh = (int)std::lrint(h * scale);
-            // flow of this level: zero at the coarsest, else the coarser level's flow resized and doubled
-            if (k == levels) {
-                HIPCHK(c, hipMemsetAsync(flow, 0, sizeof(float) * 2 * (size_t)lw * lh * pairs, st));
-            } else {
-                fb_resize_tabs T;
-                if ((rc = get_fb_tabs(c, ph, pw, lh, lw, T))) return rc;
-                launch_fb_resize(st, prev_flow, ph, pw, 2, flow, lh, lw, pairs, T, (float)(1. / pyr_scale), true);
-            }
+            // flow of this level: zero at the coarsest, else the coarser level's flow resized and doubled — formed
+            // inside the level's first product rebuild (its only reader), never written out
+            fb_resize_tabs TF;
+            const bool coarsest = (k == levels);
+            // exact 2x decimation cannot occur here (this is an upscale), so the bilinear tables always apply
+            if (!coarsest && (rc = get_fb_tabs(c, ph, pw, lh, lw, TF))) return rc;
             // every plane once: blur (only where the resize will sample), resize to the level, polynomial expansion
             const float *level_img = blur;
             if (lw != w || lh != h) {
@@ -379,7 +377,7 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
                                tmp, blur);
             }
             launch_fb_polyexp(st, level_img, planes, lh, lw, PC, R);
-            launch_fb_update(st, R, flow, pairs, lh, lw, M);
+            launch_fb_update_first(st, R, coarsest ? nullptr : prev_flow, ph, pw, TF, (float)(1. / pyr_scale), pairs, lh, lw, M);
             for (int i = 0; i < iters; i++) {
                 launch_fb_blur_solve(st, M, pairs, lh, lw, flow);
                 if (i < iters - 1) launch_fb_update(st, R, flow, pairs, lh, lw, M);

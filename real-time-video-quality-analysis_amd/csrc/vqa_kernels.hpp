@@ -80,6 +80,8 @@ void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, 
                       const fb_resize_tabs &T, float mul, bool apply_mul);
 void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out);
 void launch_fb_update(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *M);
+void launch_fb_update_first(hipStream_t st, const float *R, const float *coarse, int ch, int cw, const fb_resize_tabs &T,
+                            float mul, int pairs, int h, int w, float *M);
 void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int w, float *flow);
 int fb_mag_blocks();
 void launch_fb_mag(hipStream_t st, const float *flow, int pairs, int h, int w, double *partials, bool first_valid,
