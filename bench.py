@@ -300,8 +300,8 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "alg_bytes": alg_bytes[dom],
                     "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"
-                            + ("; k_ssim_gauss is VALU-bound by construction: 79% VALU-busy at 0.66 TB/s "
-                               "(DESIGN.md section 5)" if dom == "k_ssim_gauss" else "")}
+                            + ("; k_ssim_gauss is VALU-bound by construction: 88% VALU-busy by the PMC counters "
+                               "(profiles/round1_c3_valu.json, DESIGN.md section 5)" if dom == "k_ssim_gauss" else "")}
         line = {
             "metric": "frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
