@@ -50,6 +50,24 @@ for case in range(n_cases):
             nb, sad, hist = co.block_sad(gp, g, rng_)
             assert (int(rec[i]["sad_sum"]), int(rec[i]["sad_blocks"])) == (sad, nb) and (rec[i]["mv_d2_hist"] == hist).all(), ("sad", ctx)
         assert int(rec[i]["orb_keypoints"]) == co.orb64_count(co.bgr2gray(co.resize_linear(fr[i + 1], 64, 64)))[0], ("orb", ctx)
+    if case % 7 == 0:  # the full-frame cv2.dct parity mode: VALU tiles below 128x128, MFMA tiles above
+        fw, fh = int(r.integers(1, 260)), int(r.integers(1, 200))
+        rec = eng.complexity(fr[1:], prev0=fr[0], mask=N.M_DCT | N.M_TEMPORAL_DCT, resize=(fw, fh), dct_mode=N.DCT_FULL)
+        for i in range(n):
+            a, p_ = co.resize_linear(co.bgr2gray(fr[i + 1]), fw, fh), co.resize_linear(co.bgr2gray(fr[i]), fw, fh)
+            e, l1 = co.dct_energy_full(a), co.temporal_dct_full(p_, a)
+            assert e == 0 or abs(rec[i]["dct_energy"] - e) <= RT * e, ("dct_full", case, h, w, fw, fh, rec[i]["dct_energy"], e)
+            assert l1 == 0 or abs(rec[i]["temporal_dct_l1"] - l1) <= RT * l1, ("tdct_full", case, h, w, fw, fh, rec[i]["temporal_dct_l1"], l1)
+    if case % 11 == 0 and h > 8 and w > 8:  # region of interest in place, host and device resident
+        y0, x0 = int(r.integers(0, h // 2)), int(r.integers(0, w // 2))
+        y1, x1 = int(r.integers(y0 + 1, h + 1)), int(r.integers(x0 + 1, w + 1))
+        sub = fr[:, y0:y1, x0:x1]
+        want = eng.complexity(np.ascontiguousarray(sub[1:]), prev0=np.ascontiguousarray(sub[0]), mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        dev = eng.upload(fr).roi(y0, y1, x0, x1)
+        for got in (eng.complexity(sub[1:], prev0=sub[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8),
+                    eng.complexity(dev.slice(1, n + 1), prev0=dev.frame(0), mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)):
+            for f in want.dtype.names:
+                assert f == "hyst_steps" or (got[f] == want[f]).all(), ("roi", case, h, w, y0, y1, x0, x1, f)
     if h >= 11 and w >= 11:
         for mode, fn in ((N.SSIM_GAUSS, co.ssim_gauss), (N.SSIM_FFMPEG, co.ssim_ffmpeg)):
             q = eng.quality(fr[:-1], fr[1:], bgr_planes(h, w), mode)
