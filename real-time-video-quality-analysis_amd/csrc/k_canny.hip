@@ -182,10 +182,12 @@ __device__ __forceinline__ void nms2_step(nms_rows &S, int j, const uint8_t *__r
     const int R = y0 - 2 + j;
     // ---- horizontal partial sums of gray row R (vertical border: replicate)
     {
-        const uint8_t *row = g + (int64_t)min(max(R, 0), h - 1) * pitch;
+        // wave-uniform row base in scalar registers + 32-bit clamped column offsets (loop-invariant): the loads
+        // take the saddr form and cost no vector ALU work for addressing
+        const gptr_u8 row = uniform_ptr(g + (int64_t)min(max(R, 0), h - 1) * pitch);
         int p[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) p[k] = row[min(max(xm2 + k, 0), w - 1)];
+        for (int k = 0; k < 8; k++) p[k] = row[(uint32_t)min(max(xm2 + k, 0), w - 1)];
         const s2 P0 = {(short)p[0], (short)p[1]}, Q0 = {(short)p[1], (short)p[2]}, P1 = {(short)p[2], (short)p[3]};
         const s2 Q1 = {(short)p[3], (short)p[4]}, P2 = {(short)p[4], (short)p[5]}, Q2 = {(short)p[5], (short)p[6]};
         const s2 P3 = {(short)p[6], (short)p[7]};

@@ -116,9 +116,12 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
     const bool in_c = xin < w;
     const bool own_c = in_c && (last_cb || t < QOUT);
     const bool out_c = (t < QOUT) && (xin < ow);
-    const int64_t base = g.offset[ch] + (int64_t)ys * row_stride + (int64_t)(in_c ? xin : 0) * step;
-    const uint8_t *rp = ref + (int64_t)f * ref_fs + base;
-    const uint8_t *dp = dist + (int64_t)f * dist_fs + base;
+    // wave-uniform row base (scalar registers) + a per-thread 32-bit column offset that never changes: the
+    // row-to-row address arithmetic stays on the scalar unit, the vector ALUs only see the loads
+    const int64_t base = g.offset[ch] + (int64_t)ys * row_stride;
+    const uint8_t *rbase = ref + (int64_t)f * ref_fs + base;
+    const uint8_t *dbase = dist + (int64_t)f * dist_fs + base;
+    const uint32_t coff = (uint32_t)((in_c ? xin : 0) * step);
 
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 acc[11]; // .xy = (E[x], E[y]) column sums, .zw = (E[x^2+y^2], E[xy]): one ds_write_b128 per row, no repacking
@@ -132,8 +135,8 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
 #pragma unroll
     for (int i = 0; i < PF; i++) {
         const int rr = min(i, nrows - 1);
-        qr[i] = rp[(int64_t)rr * row_stride];
-        qd[i] = dp[(int64_t)rr * row_stride];
+        qr[i] = uniform_ptr(rbase + (int64_t)rr * row_stride)[coff];
+        qd[i] = uniform_ptr(dbase + (int64_t)rr * row_stride)[coff];
     }
     for (int r0 = 0; r0 < nrows; r0 += 11) {
 #pragma unroll
@@ -145,12 +148,12 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
                 for (int i = 0; i + 1 < PF; i++) { qr[i] = qr[i + 1]; qd[i] = qd[i + 1]; }
                 {
                     const int rr = min(r + PF, nrows - 1);
-                    qr[PF - 1] = rp[(int64_t)rr * row_stride];
-                    qd[PF - 1] = dp[(int64_t)rr * row_stride];
+                    qr[PF - 1] = uniform_ptr(rbase + (int64_t)rr * row_stride)[coff];
+                    qd[PF - 1] = uniform_ptr(dbase + (int64_t)rr * row_stride)[coff];
                 }
                 if (own_c && (last_sb || r < QS)) {
                     const int e = (int)cr - (int)cd;
-                    sse_acc += (uint32_t)(e * e);
+                    sse_acc += (uint32_t)__mul24(e, e);
                 }
                 const f2 xy = f2{(float)cr, (float)cd} - f2{128.f, 128.f};
                 f2 v1 = xy.xx * xy;                                        // (x^2, x y)

@@ -44,6 +44,16 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
     return t;
 }
 
+// A pointer that is wave-uniform by construction, pinned to scalar registers, in the global address space:
+// `uniform_ptr(base)[lane_offset_u32]` compiles to global_load ... v_off, s[base] (no vector ALU address math).
+typedef const __attribute__((address_space(1))) uint8_t *gptr_u8;
+__device__ __forceinline__ gptr_u8 uniform_ptr(const uint8_t *p)
+{
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (gptr_u8)(((uint64_t)hi << 32) | lo);
+}
+
 // cv2.cvtColor BGR2GRAY, uint8: 15-bit fixed point (complexity_metrics.py:358 et al.)
 __device__ __forceinline__ uint32_t gray_u8(uint32_t b, uint32_t g, uint32_t r)
 {
