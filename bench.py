@@ -300,7 +300,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "alg_bytes": alg_bytes[dom],
                     "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"
-                            + ("; k_ssim_gauss is VALU-bound by construction: 88% VALU-busy by the PMC counters "
+                            + ("; k_ssim_gauss is VALU-bound by construction: 83% VALU-busy by the PMC counters, LDS bandwidth close behind "
                                "(profiles/round1_c3_valu.json, DESIGN.md section 5)" if dom == "k_ssim_gauss" else "")}
         line = {
             "metric": "frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
