@@ -6,22 +6,29 @@
          --master-port P bench.py --gpus N --steps K --warmup W   (N > 1, one rank per GPU)
 
 A "step" is one pass of the selected workload over one device-resident batch of
-frames.  Rank 0 prints ONE JSON line (contract in the task statement) with two
-extra objects: "roofline" (dominant kernel, algorithmic bytes / HIP-event time)
-and, at N = 1, "cpu_baseline" (the oracle port under a process pool that
-reproduces the reference's process_in_batches, timed on this box's host cores).
+frames.  Rank 0 prints ONE JSON line (contract in the task statement) with three
+extra objects: "roofline" (dominant kernel, algorithmic bytes / HIP-event time),
+"end_to_end" (the same workload fed from pinned host memory over PCIe, measured
+after the timed region; never `value`) and, at N = 1, "cpu_baseline" (the oracle
+port under a process pool that reproduces the reference's process_in_batches,
+timed on this box's host cores).
 
 Workloads (BASELINE.json configs):
-  c2  1920x1080, frame_interval=1, PSNR + SSIM (Gaussian) + 8x8 DCT (energy + temporal)   [default]
-  c3  1920x1080 full complexity suite + PSNR/SSIM
+  c3  1920x1080 full complexity suite + PSNR/SSIM          [default: the config BASELINE.json's metric is quoted on]
+  c2  1920x1080, frame_interval=1, PSNR + SSIM (Gaussian) + 8x8 DCT (energy + temporal)
   c4  3840x2160 full suite
 Frame streams shard one-stream-per-GPU (weak scaling): every rank runs the same
 workload on its own stream; the only cross-rank traffic is one scalar
-all-reduce (RCCL) of the pooled metrics after the timed region.
+all-reduce (RCCL) of the pooled metrics after the timed region.  An RCCL failure
+at N > 1 is fatal on every rank (exit code 3) unless VQA_BENCH_DEVICE pins the
+ranks to one device, which is the 1-GPU rehearsal of the rank logic.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -32,6 +39,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+CSRC = os.path.join(REPO, "real-time-video-quality-analysis_amd", "csrc")
 
 WORKLOADS = {
     "c2": dict(h=1080, w=1920, batch=256, full=False,
@@ -66,16 +74,33 @@ def _cpu_item(item):
     return out
 
 
-def cpu_baseline(ref, dist, full, sample, motion="sad"):
+def visible_cores():
+    try:
+        return len(os.sched_getaffinity(0))  # the cores this process may run on
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_workers(cores):
+    """num_workers exactly as the reference picks it (complexity_metrics.py:264-265): cores // 2.
+    VQA_CPU_WORKERS overrides it explicitly (reported as workers_override)."""
+    ov = os.environ.get("VQA_CPU_WORKERS")
+    if ov:
+        return max(1, int(ov)), True
+    return max(1, cores // 2), False
+
+
+def cpu_baseline(h, w, full, sample, motion="sad"):
     from concurrent.futures import ProcessPoolExecutor
     from oracle import c_oracle as co
+    from rtvqa_amd import synth
     co.build()
-    try:
-        cores = len(os.sched_getaffinity(0))  # this job's CPU share, not the whole host
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = min(cores, int(os.environ.get("VQA_CPU_CORES", "16")))  # a 1-GPU box's share is 16 cores
-    workers = max(1, cores // 2)  # complexity_metrics.py:264-265
+    cores = visible_cores()
+    workers, override = cpu_workers(cores)
+    if sample <= 0:  # bounded sample: every worker gets a few items, ~10-30 s of CPU work at 1080p
+        sample = max(32, 3 * workers)
+    ref = synth.s_natural(sample, h, w, seed=1234, stream_id=0, t0=0)
+    dist = synth.distort(ref, t0=0)
     items = [(ref[i], dist[i], dist[i - 1] if i else dist[0], full, motion) for i in range(sample)]
     t0 = time.perf_counter()
     results = []
@@ -83,9 +108,143 @@ def cpu_baseline(ref, dist, full, sample, motion="sad"):
         for i in range(0, len(items), 100):  # batch_size=100, barrier per batch (:144-147)
             results.extend(ex.map(_cpu_item, items[i:i + 100]))
     dt = time.perf_counter() - t0
-    return dict(value=round(sample / dt, 3), unit="frames/s", cores=workers, kind="port",
+    return dict(value=round(sample / dt, 3), unit="frames/s", cores=cores, workers=workers, workers_override=override,
+                kind="port", seconds=round(dt, 2),
                 sample="%d frame pairs of the same workload, oracle/ C port under ProcessPoolExecutor(max_workers="
-                       "cpu_count//2=%d of %d cores), chunksize 1, batch_size 100" % (sample, workers, cores))
+                       "cores//2 = %d of the %d cores visible to the process), chunksize 1, batch_size 100"
+                       % (sample, workers, cores))
+
+
+# ---------------------------------------------------------------------------
+# PMC traffic of the dominant kernel: a committed profiles/round<NN>_<workload>_pmc.json is used only while
+# the kernel sources it was collected on are byte-identical to the ones this run loads.
+# ---------------------------------------------------------------------------
+def source_hashes():
+    out = {}
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))):
+        out[os.path.basename(f)] = hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
+    return out
+
+
+KERNEL_SOURCES = {"k_ssim_gauss": ["k_quality.hip"], "k_ssim_ffmpeg": ["k_quality.hip"], "k_dct8": ["k_dct8.hip", "vqa_math.hpp"],
+                  "k_bgr2gray_hist": ["k_gray_hist.hip"], "k_canny_nms": ["k_canny.hip"], "k_block_sad": ["k_sad.hip"]}
+
+
+def pmc_traffic(workload, kernel, frames_per_launch, default_mode):
+    """(bytes per launch or None, traffic_source string)"""
+    if not default_mode:
+        return None, "none: PMC passes are collected for the default modes only"
+    cands = []
+    for p in glob.glob(os.path.join(REPO, "profiles", "round*_%s_pmc.json" % workload)):
+        m = re.match(r"round(\d+)_", os.path.basename(p))
+        if m:
+            cands.append((int(m.group(1)), p))
+    if not cands:
+        return None, "none: no profiles/round*_%s_pmc.json" % workload
+    _, path = max(cands)
+    pmc = json.load(open(path))
+    rel = os.path.relpath(path, REPO)
+    want = pmc.get("source_sha256")
+    if not want:
+        return None, "stale: %s carries no source hashes (collected before the kernels were stamped)" % rel
+    have = source_hashes()
+    for f in KERNEL_SOURCES.get(kernel, []) + ["vqa_dev.hpp"]:
+        if want.get(f) != have.get(f):
+            return None, "stale: %s was collected on a different %s (@ %s)" % (rel, f, pmc.get("git_sha", "?"))
+    for kname, ent in pmc["kernels"].items():
+        if kname.split("<")[0] == kernel or (kernel == "k_canny_nms" and kname.startswith("k_canny_nms")) \
+                or (kernel == "k_dct8" and kname.startswith("k_dct8")):
+            return int(ent["hbm_bytes"] * frames_per_launch / pmc["frames_per_launch"]), "%s @ %s" % (rel, pmc.get("git_sha", "?"))
+    return None, "none: %s has no entry for %s" % (rel, kernel)
+
+
+# ---------------------------------------------------------------------------
+# torch.distributed bring-up for N > 1.  RCCL must work: a failure is fatal on every rank unless the ranks were
+# deliberately pinned to one device (VQA_BENCH_DEVICE: the 1-GPU rehearsal), where RCCL refuses duplicate GPUs.
+# ---------------------------------------------------------------------------
+def init_dist(backend, rank, world, device, rehearsal, stub):
+    """returns (td, backend_used, reduce_device, rccl_ranks)"""
+    import datetime
+    import torch
+    import torch.distributed as td
+    tmo = datetime.timedelta(seconds=300)
+    if backend == "gloo":
+        td.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+        return td, "gloo", "cpu", None
+    try:  # device_id makes the RCCL communicator come up here, so a broken fabric shows now, on every rank
+        td.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo, device_id=torch.device("cuda", device))
+        probe = torch.ones(1, device="cuda")
+        td.all_reduce(probe)
+        torch.cuda.synchronize()
+        got = int(probe.item())
+        if got != world:
+            raise RuntimeError("probe all-reduce returned %d, expected %d" % (got, world))
+        return td, "nccl", "cuda", got
+    except Exception as e:
+        if not rehearsal:
+            sys.stderr.write("[bench] rank %d: FATAL: RCCL bring-up failed on device %d: %s\n" % (rank, device, e))
+            sys.stderr.flush()
+            os._exit(3)  # every rank takes this path (the failure is collective); no JSON line is printed
+        sys.stderr.write("[bench] rank %d: rehearsal (VQA_BENCH_DEVICE=%d): RCCL refused (%s); scalar reductions over gloo\n"
+                         % (rank, device, str(e).splitlines()[0][:160]))
+        if td.is_initialized():
+            try:
+                td.destroy_process_group()
+            except Exception:
+                pass
+        td.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+        return td, "gloo", "cpu", None
+
+
+class StubEngine:
+    """--stub-engine: stands in for the HIP engine so the N > 1 rank logic (barriers, max-over-ranks timing, scalar
+    all-reduce, JSON shape) can be rehearsed on a CPU under gloo.  It computes nothing; the line says "stub": true."""
+
+    def __init__(self, batch):
+        self.batch = batch
+
+    def step(self):
+        time.sleep(0.002)
+        return ({"ssim": np.full((self.batch, 3), 0.5)}, {"dct_energy": np.full(self.batch, 1.0)})
+
+
+# ---------------------------------------------------------------------------
+def end_to_end(rtvqa_amd, N, device, eng, ref_pin, dist_pin, h, w, full, mask, params, planes, smode, steps):
+    """The same workload fed from PINNED HOST memory every step: each buffer crosses PCIe once (vqa_copy_h2d on the
+    context's stream), two contexts are ping-ponged so the copy of batch i+1 overlaps the kernels of batch i."""
+    from rtvqa_amd.engine import DeviceBuffer, DeviceFrames
+    Be = ref_pin.shape[0] - 1
+    fb = h * w * 3
+    engs = [eng, rtvqa_amd.Engine(device)]
+    dbufs = [(DeviceBuffer(e, fb * (Be + 1)), DeviceBuffer(e, fb * (Be + 1))) for e in engs]
+
+    def submit(i):
+        e = engs[i & 1]
+        dr, dd = dbufs[i & 1]
+        N.check(e.lib.vqa_copy_h2d(e.ctx, dr.ptr, ref_pin.ctypes.data, ref_pin.nbytes), "h2d", e.ctx)
+        N.check(e.lib.vqa_copy_h2d(e.ctx, dd.ptr, dist_pin.ctypes.data, dist_pin.nbytes), "h2d", e.ctx)
+        fr, fd = DeviceFrames(dr.ptr, Be + 1, h, w, owner=dr), DeviceFrames(dd.ptr, Be + 1, h, w, owner=dd)
+        e.quality_submit(fr.slice(1, Be + 1), fd.slice(1, Be + 1), planes, smode)
+        e.complexity_submit(fd.slice(1, Be + 1), fd.frame(0), mask, params)
+
+    def wait(i):
+        e = engs[i & 1]
+        return e.quality_wait(), e.complexity_wait()
+
+    submit(0); wait(0); submit(1); wait(1)  # warm both contexts (allocations, first-touch)
+    t0 = time.perf_counter()
+    submit(0)
+    for i in range(1, steps):
+        submit(i)
+        wait(i - 1)
+    wait(steps - 1)
+    dt = time.perf_counter() - t0
+    engs[1].close()
+    gb = 2.0 * fb * (Be + 1) * steps / 1e9
+    return dict(fps=round(Be * steps / dt, 1), h2d_GBps=round(gb / dt, 2), pinned=True,
+                overlap="2 contexts ping-ponged: H2D of batch i+1 overlaps the kernels of batch i",
+                frames_per_step=Be, steps=steps,
+                note="PCIe Gen5 x16 bound (12.4 MB per 1080p BGR frame pair); measured after the timed region, never `value`")
 
 
 # ---------------------------------------------------------------------------
@@ -94,9 +253,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS),
+                    help="c3 (default) = BASELINE.json's headline: 1080p full suite + PSNR/SSIM; c2 = PSNR+SSIM+8x8 DCT only; c4 = 2160p full suite")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="frame pairs for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="frame pairs for the CPU baseline (0 = skip, -1 = auto)")
+    ap.add_argument("--e2e-steps", type=int, default=6, help="steps of the PCIe-inclusive end_to_end measurement (0 = skip)")
+    ap.add_argument("--e2e-batch", type=int, default=64, help="frames per step of the end_to_end measurement")
     ap.add_argument("--ssim-mode", default="gauss", choices=["gauss", "ffmpeg"])
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="1 (default): one stream, clean per-kernel event times; 2: quality kernels on a second stream (+4-8%% fps, event times of overlapped kernels are inflated)")
@@ -111,6 +273,8 @@ def main():
                     help="motion metric of the full suite: sad (north_star's block-SAD, default) or farneback (the reference's own)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the rank logic)")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="CPU rehearsal of the N > 1 rank logic under gloo: no kernels run, the line carries \"stub\": true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,130 +282,138 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.stub_engine and args.backend != "gloo":
+        raise SystemExit("--stub-engine is a CPU rehearsal: use --backend gloo")
 
     wl = WORKLOADS[args.workload]
     h, w, full = wl["h"], wl["w"], wl["full"]
     B = args.batch or wl["batch"]
+    stub = args.stub_engine
 
     # CPU baseline first: its worker processes are forked before this process touches the GPU
     cpu_line = None
-    if world == 1 and rank == 0 and args.cpu_sample != 0:
-        from rtvqa_amd import synth as _synth
-        sample = args.cpu_sample if args.cpu_sample > 0 else 32
-        r = _synth.s_natural(sample, h, w, seed=1234, stream_id=0, t0=0)
-        cpu_line = cpu_baseline(r, _synth.distort(r, t0=0), full, sample, args.motion)
-        del r
+    if world == 1 and rank == 0 and args.cpu_sample != 0 and not stub:
+        cpu_line = cpu_baseline(h, w, full, args.cpu_sample, args.motion)
 
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    # VQA_BENCH_DEVICE pins every rank to one device: only for rehearsing the N > 1 logic on a 1-GPU box (gloo)
+    rehearsal = "VQA_BENCH_DEVICE" in os.environ
     device = int(os.environ.get("VQA_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(device)
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+        # VQA_BENCH_DEVICE pins every rank to one device: only for rehearsing the N > 1 logic on a 1-GPU box
+        torch.cuda.set_device(device)
     dist_on = world > 1
-    red_dev = "cuda" if args.backend == "nccl" else "cpu"
+    td, backend_used, red_dev, rccl_ranks = None, None, "cpu", None
     if dist_on:
-        import torch.distributed as td
-        import datetime
-        tmo = datetime.timedelta(seconds=300)
-        if args.backend == "nccl":
-            try:  # device_id makes the RCCL communicator come up here, so a broken fabric shows now, on every rank
-                td.init_process_group("nccl", rank=rank, world_size=world, timeout=tmo,
-                                      device_id=torch.device("cuda", device))
-                probe = torch.ones(1, device="cuda")
-                td.all_reduce(probe)
-                assert int(probe.item()) == world
-            except Exception as e:  # the two scalar reductions of this path do not need xGMI: finish over gloo
-                sys.stderr.write("[bench] rank %d: RCCL unavailable (%s); using gloo for the scalar reductions\n" % (rank, e))
-                if td.is_initialized():
-                    td.destroy_process_group()
-                args.backend, red_dev = "gloo", "cpu"
-                td.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
-        else:
-            td.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+        td, backend_used, red_dev, rccl_ranks = init_dist(args.backend, rank, world, device, rehearsal, stub)
 
-    import rtvqa_amd
-    from rtvqa_amd import _native as N
-    from rtvqa_amd import synth
-    from rtvqa_amd.engine import DeviceBuffer, DeviceFrames, bgr_planes, yuv420p_planes
-    from rtvqa_amd.frames import bgr_to_yuv420p, frame_bytes_yuv420p
+    def sync_device():
+        if not stub:
+            torch.cuda.synchronize()
 
-    # two contexts = two HIP streams on the same device: the VALU-bound SSIM launch overlaps the
-    # memory/latency-bound complexity kernels and the host round-trips of the Canny fixpoint
-    eng = rtvqa_amd.Engine(device)
-    eng_q = rtvqa_amd.Engine(device) if args.streams == 2 else eng
+    if stub:
+        eng = eng_q = None
+        se = StubEngine(B)
+        step = se.step
 
-    # ---- synthetic streams, generated in chunks and made resident in HBM before timing
-    fbytes = h * w * 3
-    ref_buf, dist_buf = DeviceBuffer(eng, fbytes * (B + 1)), DeviceBuffer(eng, fbytes * (B + 1))
-    yuv = args.pixfmt == "yuv420p"
-    ybytes = frame_bytes_yuv420p(h, w)
-    if yuv:
-        yref_buf, ydist_buf = DeviceBuffer(eng, ybytes * (B + 1)), DeviceBuffer(eng, ybytes * (B + 1))
-    chunk = 32
-    for a in range(0, B + 1, chunk):
-        n = min(chunk, B + 1 - a)
-        r = (synth.s_natural(n, h, w, seed=1234, stream_id=rank, t0=a) if args.content == "natural"
-             else synth.s_noise(n, h, w, seed=1234 + a, stream_id=rank))
-        d = synth.distort(r, t0=a)
-        N.check(eng.lib.vqa_copy_h2d(eng.ctx, ref_buf.ptr + a * fbytes, r.ctypes.data, r.nbytes), "h2d", eng.ctx)
-        N.check(eng.lib.vqa_copy_h2d(eng.ctx, dist_buf.ptr + a * fbytes, d.ctypes.data, d.nbytes), "h2d", eng.ctx)
-        if yuv:
-            yr, yd = bgr_to_yuv420p(r), bgr_to_yuv420p(d)
-            N.check(eng.lib.vqa_copy_h2d(eng.ctx, yref_buf.ptr + a * ybytes, yr.ctypes.data, yr.nbytes), "h2d", eng.ctx)
-            N.check(eng.lib.vqa_copy_h2d(eng.ctx, ydist_buf.ptr + a * ybytes, yd.ctypes.data, yd.nbytes), "h2d", eng.ctx)
-        eng.sync()
-    ref_all = DeviceFrames(ref_buf.ptr, B + 1, h, w, owner=ref_buf)
-    dist_all = DeviceFrames(dist_buf.ptr, B + 1, h, w, owner=dist_buf)
-    ref_b, dist_b, prev0 = ref_all.slice(1, B + 1), dist_all.slice(1, B + 1), dist_all.frame(0)
-
-    mask = N.M_ALL if full else (N.M_DCT | N.M_TEMPORAL_DCT)
-    params = eng.make_params(dct_mode=N.DCT_BLOCK8 if args.dct_mode == "block8" else N.DCT_FULL,
-                             motion_mode=N.MOTION_FARNEBACK if args.motion == "farneback" else N.MOTION_SAD)
-    planes = bgr_planes(h, w)
-    if yuv:  # quality kernels read the planar streams; the complexity kernels still read the BGR frames
-        planes = yuv420p_planes(h, w)
-        ref_b = DeviceFrames(yref_buf.ptr + ybytes, B, h, w, frame_stride=ybytes, row_stride=w, owner=yref_buf, channels=1)
-        dist_q = DeviceFrames(ydist_buf.ptr + ybytes, B, h, w, frame_stride=ybytes, row_stride=w, owner=ydist_buf, channels=1)
+        def fence():
+            if dist_on:
+                td.barrier()
+        prof = {}
     else:
-        dist_q = dist_b
-    smode = N.SSIM_GAUSS if args.ssim_mode == "gauss" else N.SSIM_FFMPEG
+        import rtvqa_amd
+        from rtvqa_amd import _native as N
+        from rtvqa_amd import synth
+        from rtvqa_amd.engine import DeviceBuffer, DeviceFrames, bgr_planes, yuv420p_planes
+        from rtvqa_amd.frames import bgr_to_yuv420p, frame_bytes_yuv420p
 
-    def step():
-        eng_q.quality_submit(ref_b, dist_q, planes, smode)
-        eng.complexity_submit(dist_b, prev0, mask, params)
-        q = eng_q.quality_wait()
-        c = eng.complexity_wait()
-        return q, c
+        # two contexts = two HIP streams on the same device (--streams 2)
+        eng = rtvqa_amd.Engine(device)
+        eng_q = rtvqa_amd.Engine(device) if args.streams == 2 else eng
 
-    def fence():
-        eng.sync()
-        eng_q.sync()
-        torch.cuda.synchronize()
-        if dist_on:
-            td.barrier()
-        torch.cuda.synchronize()
+        # ---- synthetic streams, generated in chunks and made resident in HBM before timing
+        fbytes = h * w * 3
+        ref_buf, dist_buf = DeviceBuffer(eng, fbytes * (B + 1)), DeviceBuffer(eng, fbytes * (B + 1))
+        yuv = args.pixfmt == "yuv420p"
+        ybytes = frame_bytes_yuv420p(h, w)
+        if yuv:
+            yref_buf, ydist_buf = DeviceBuffer(eng, ybytes * (B + 1)), DeviceBuffer(eng, ybytes * (B + 1))
+        do_e2e = rank == 0 and args.e2e_steps > 0 and not yuv
+        Be = min(args.e2e_batch, B)
+        if do_e2e:  # page-locked host copies of the first Be+1 frames for the end_to_end measurement
+            ref_pin, dist_pin = eng.alloc_pinned((Be + 1, h, w, 3)), eng.alloc_pinned((Be + 1, h, w, 3))
+        chunk = 32
+        for a in range(0, B + 1, chunk):
+            n = min(chunk, B + 1 - a)
+            r = (synth.s_natural(n, h, w, seed=1234, stream_id=rank, t0=a) if args.content == "natural"
+                 else synth.s_noise(n, h, w, seed=1234 + a, stream_id=rank))
+            d = synth.distort(r, t0=a)
+            N.check(eng.lib.vqa_copy_h2d(eng.ctx, ref_buf.ptr + a * fbytes, r.ctypes.data, r.nbytes), "h2d", eng.ctx)
+            N.check(eng.lib.vqa_copy_h2d(eng.ctx, dist_buf.ptr + a * fbytes, d.ctypes.data, d.nbytes), "h2d", eng.ctx)
+            if yuv:
+                yr, yd = bgr_to_yuv420p(r), bgr_to_yuv420p(d)
+                N.check(eng.lib.vqa_copy_h2d(eng.ctx, yref_buf.ptr + a * ybytes, yr.ctypes.data, yr.nbytes), "h2d", eng.ctx)
+                N.check(eng.lib.vqa_copy_h2d(eng.ctx, ydist_buf.ptr + a * ybytes, yd.ctypes.data, yd.nbytes), "h2d", eng.ctx)
+            eng.sync()
+            if do_e2e and a <= Be:
+                m = min(n, Be + 1 - a)
+                ref_pin[a:a + m] = r[:m]
+                dist_pin[a:a + m] = d[:m]
+        ref_all = DeviceFrames(ref_buf.ptr, B + 1, h, w, owner=ref_buf)
+        dist_all = DeviceFrames(dist_buf.ptr, B + 1, h, w, owner=dist_buf)
+        ref_b, dist_b, prev0 = ref_all.slice(1, B + 1), dist_all.slice(1, B + 1), dist_all.frame(0)
+
+        mask = N.M_ALL if full else (N.M_DCT | N.M_TEMPORAL_DCT)
+        params = eng.make_params(dct_mode=N.DCT_BLOCK8 if args.dct_mode == "block8" else N.DCT_FULL,
+                                 motion_mode=N.MOTION_FARNEBACK if args.motion == "farneback" else N.MOTION_SAD)
+        planes = bgr_planes(h, w)
+        if yuv:  # quality kernels read the planar streams; the complexity kernels still read the BGR frames
+            planes = yuv420p_planes(h, w)
+            ref_b = DeviceFrames(yref_buf.ptr + ybytes, B, h, w, frame_stride=ybytes, row_stride=w, owner=yref_buf, channels=1)
+            dist_q = DeviceFrames(ydist_buf.ptr + ybytes, B, h, w, frame_stride=ybytes, row_stride=w, owner=ydist_buf, channels=1)
+        else:
+            dist_q = dist_b
+        smode = N.SSIM_GAUSS if args.ssim_mode == "gauss" else N.SSIM_FFMPEG
+
+        def step():
+            eng_q.quality_submit(ref_b, dist_q, planes, smode)
+            eng.complexity_submit(dist_b, prev0, mask, params)
+            q = eng_q.quality_wait()
+            c = eng.complexity_wait()
+            return q, c
+
+        def fence():
+            eng.sync()
+            eng_q.sync()
+            torch.cuda.synchronize()
+            if dist_on:
+                td.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    eng.profile(True)
-    eng.profile_read(reset=True)
-    if eng_q is not eng:
-        eng_q.profile(True)
-        eng_q.profile_read(reset=True)
+    if not stub:
+        eng.profile(True)
+        eng.profile_read(reset=True)
+        if eng_q is not eng:
+            eng_q.profile(True)
+            eng_q.profile_read(reset=True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         q, c = step()
     fence()
     dt = time.perf_counter() - t0
-    prof = eng.profile_read(reset=True)
-    eng.profile(False)
-    if eng_q is not eng:
-        prof.update(eng_q.profile_read(reset=True))  # NOTE: with 2 streams a launch's event time includes sharing the GPU
-        eng_q.profile(False)
+    if not stub:
+        prof = eng.profile_read(reset=True)
+        eng.profile(False)
+        if eng_q is not eng:
+            prof.update(eng_q.profile_read(reset=True))  # NOTE: with 2 streams a launch's event time includes sharing the GPU
+            eng_q.profile(False)
 
     # ---- max over ranks, and the one scalar all-reduce the path has (pooled metrics)
+    devices = [device]
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -249,79 +421,94 @@ def main():
         pooled = torch.tensor([float(q["ssim"].mean()), float(c["dct_energy"].mean()), float(B)],
                               dtype=torch.float64, device=red_dev)
         td.all_reduce(pooled, op=td.ReduceOp.SUM)  # RCCL over xGMI: 24 bytes, latency-bound
+        seen = [None] * world
+        td.all_gather_object(seen, device)
+        devices = sorted(set(int(x) for x in seen))
+        if not rehearsal and not stub and len(devices) != world:
+            sys.stderr.write("[bench] FATAL: %d ranks share %d devices %s\n" % (world, len(devices), devices))
+            os._exit(3)
     frames_total = B * args.steps * world
     value = frames_total / dt
 
     if rank == 0:
-        P = h * w
-        alg_bytes = {  # algorithmic HBM bytes per profiled launch group (SURVEY.md §8d x frames per launch)
-            # bgr24: ONE launch covers the B, G, R planes (2P each).  yuv420p: two launches per step (Y: 2P,
-            # U+V: 2 * 2 * P/4), so the mean launch moves 1.5P per frame
-            "k_ssim_gauss": 2 * P * B * 3 if not yuv else int(1.5 * P * B),
-            "k_ssim_ffmpeg": 2 * P * B * 3 if not yuv else P * B,  # yuv420p: three planar launches, 3P in all
-            "k_dct8": 2 * P * B, "k_bgr2gray_hist": 4 * P * (B + 1),
-            "k_canny_nms": P * B + P * B // 4,  # reads gray, writes two bit-planes (P/8 each)
-            "k_block_sad": 2 * P * B,
-            # Farneback, per level-0 pixel and pair, every kernel reading its inputs and writing its outputs once:
-            # expansion 24 B + 3 x (product rebuild 68 B + box/solve 28 B) = 312 B, x 4/3 for the pyramid, + ~25 B of blur
-            "farneback(pyramid)": 440 * P * B,
-        }
-        kernels = {}
-        for name, (ms, cnt) in prof.items():
-            per = ms / cnt
-            ent = {"ms_per_launch": round(per, 4), "launches": cnt, "share_of_kernel_time": 0.0}
-            if name in alg_bytes:
-                gbs = alg_bytes[name] / (per * 1e-3) / 1e9
-                ent.update({"alg_bytes": alg_bytes[name], "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
-            kernels[name] = ent
-        tot = sum(ms for ms, _ in prof.values()) or 1.0
-        for name, (ms, _) in prof.items():
-            kernels[name]["share_of_kernel_time"] = round(ms / tot, 4)
-        mfma_flops = {"k_dct_full(gemm_nt x4)": 2 * 2.0 * (w * w * h + h * h * w) * B}  # energy + temporal, 2 products each
-        for name, fl in mfma_flops.items():
-            if name in kernels:
-                tf = fl / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
-                kernels[name].update({"flops": fl, "TFLOPps": round(tf, 1), "frac_mfma_f32": round(tf / 157.3, 4)})
-        dom = max((k for k in prof if k in alg_bytes or k in mfma_flops), key=lambda k: prof[k][0])
-        # HBM traffic per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of THIS
-        # command (scripts/gpu_pmc.sh), corrected as the guide prescribes and committed under profiles/
-        traffic = None
-        pmc_path = os.path.join(REPO, "profiles", "round1_%s_pmc.json" % args.workload)
-        if os.path.exists(pmc_path) and args.ssim_mode == "gauss":
-            pmc = json.load(open(pmc_path))
-            for kname, ent in pmc["kernels"].items():
-                if kname.split("<")[0] == dom:
-                    traffic = int(ent["hbm_bytes"] * B / pmc["frames_per_launch"])
-        if dom in mfma_flops:
-            roof = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": kernels[dom]["frac_mfma_f32"], "traffic": None,
-                    "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = flops per launch / mean HIP-event duration"}
-        else:
-            roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "alg_bytes": alg_bytes[dom],
-                    "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"
-                            + ("; k_ssim_gauss is VALU-bound by construction: 83% VALU-busy by the PMC counters, LDS bandwidth close behind "
-                               "(profiles/round1_c3_valu.json, DESIGN.md section 5)" if dom == "k_ssim_gauss" else "")}
         line = {
             "metric": "frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->f32 (SSE/bins/SAD exact int)",
-            "data": "synthetic (synth.s_%s v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
-                    % (args.content, synth.GENERATOR_VERSION),
-            "config": {"workload": wl["name"] if args.ssim_mode == "gauss" else
-                       wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"), "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams, "collective": (("rccl" if args.backend == "nccl" else "gloo") + " scalar all-reduce") if world > 1 else "none",
-                       "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode, "motion": args.motion, "parallelism": "1 stream/GPU x%d" % world},
-            "roofline": roof, "kernels": kernels,
         }
-        if cpu_line is not None:
-            line["cpu_baseline"] = cpu_line
-        print(json.dumps(line), flush=True)
+        config = {"workload": wl["name"] if args.ssim_mode == "gauss" else
+                  wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"),
+                  "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams,
+                  "collective": ("%s scalar all-reduce" % ("rccl" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
+                  "rccl_ranks": rccl_ranks, "devices": devices, "rehearsal_single_device": bool(rehearsal and world > 1),
+                  "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode,
+                  "motion": args.motion, "parallelism": "1 stream/GPU x%d" % world}
+        if stub:
+            line.update({"data": "STUB: no kernels ran (rank-logic rehearsal, --stub-engine)", "stub": True, "config": config,
+                         "roofline": None, "kernels": {}})
+            print(json.dumps(line), flush=True)
+        else:
+            P = h * w
+            alg_bytes = {  # algorithmic HBM bytes per profiled launch group (SURVEY.md §8d x frames per launch)
+                # bgr24: ONE launch covers the B, G, R planes (2P each).  yuv420p: two launches per step (Y: 2P,
+                # U+V: 2 * 2 * P/4), so the mean launch moves 1.5P per frame
+                "k_ssim_gauss": 2 * P * B * 3 if not yuv else int(1.5 * P * B),
+                "k_ssim_ffmpeg": 2 * P * B * 3 if not yuv else P * B,  # yuv420p: three planar launches, 3P in all
+                "k_dct8": 2 * P * B, "k_bgr2gray_hist": 4 * P * (B + 1),
+                "k_canny_nms": P * B + P * B // 4,  # reads gray, writes two bit-planes (P/8 each)
+                "k_block_sad": 2 * P * B,
+                # Farneback, per level-0 pixel and pair, every kernel reading its inputs and writing its outputs once:
+                # expansion 24 B + 3 x (product rebuild 68 B + box/solve 28 B) = 312 B, x 4/3 for the pyramid, + ~25 B of blur
+                "farneback(pyramid)": 440 * P * B,
+            }
+            kernels = {}
+            for name, (ms, cnt) in prof.items():
+                per = ms / cnt
+                ent = {"ms_per_launch": round(per, 4), "launches": cnt, "share_of_kernel_time": 0.0}
+                if name in alg_bytes:
+                    gbs = alg_bytes[name] / (per * 1e-3) / 1e9
+                    ent.update({"alg_bytes": alg_bytes[name], "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
+                kernels[name] = ent
+            tot = sum(ms for ms, _ in prof.values()) or 1.0
+            for name, (ms, _) in prof.items():
+                kernels[name]["share_of_kernel_time"] = round(ms / tot, 4)
+            mfma_flops = {"k_dct_full(gemm_nt x4)": 2 * 2.0 * (w * w * h + h * h * w) * B}  # energy + temporal, 2 products each
+            for name, fl in mfma_flops.items():
+                if name in kernels:
+                    tf = fl / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
+                    kernels[name].update({"flops": fl, "TFLOPps": round(tf, 1), "frac_mfma_f32": round(tf / 157.3, 4)})
+            dom = max((k for k in prof if k in alg_bytes or k in mfma_flops), key=lambda k: prof[k][0])
+            if dom in mfma_flops:
+                roof = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": kernels[dom]["frac_mfma_f32"], "traffic": None, "traffic_source": "none",
+                        "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = flops per launch / mean HIP-event duration"}
+            else:
+                default_mode = (args.ssim_mode == "gauss" and not yuv and args.content == "natural" and args.motion == "sad"
+                                and args.dct_mode == "block8" and args.streams == 1)
+                traffic, tsrc = pmc_traffic(args.workload, dom, B, default_mode)
+                roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "traffic_source": tsrc,
+                        "alg_bytes": alg_bytes[dom],
+                        "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"
+                                + ("; k_ssim_gauss is bound by vector-ALU issue, not HBM: 88 FMA per 2 input bytes, priced with the "
+                                   "measured issue costs of profiles/round2_valu_calib.json in DESIGN.md section 5"
+                                   if dom == "k_ssim_gauss" else "")}
+            line.update({"data": "synthetic (synth.s_%s v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
+                                 % (args.content, synth.GENERATOR_VERSION),
+                         "config": config, "roofline": roof, "kernels": kernels})
+            if do_e2e:
+                line["end_to_end"] = end_to_end(rtvqa_amd, N, device, eng, ref_pin, dist_pin, h, w, full, mask, params,
+                                                bgr_planes(h, w), smode, args.e2e_steps)
+            if cpu_line is not None:
+                line["cpu_baseline"] = cpu_line
+            print(json.dumps(line), flush=True)
     if dist_on:
         td.barrier()
         td.destroy_process_group()
-    if eng_q is not eng:
-        eng_q.close()
-    eng.close()
+    if not stub:
+        if eng_q is not eng:
+            eng_q.close()
+        eng.close()
 
 
 if __name__ == "__main__":

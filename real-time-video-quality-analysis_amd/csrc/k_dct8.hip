@@ -159,6 +159,217 @@ __global__ __launch_bounds__(256, 2) void k_dct8_pair(const uint8_t *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// Frame-marching form (default).  The reference's temporal metric is dct(prev) - dct(curr)
+// (complexity_metrics.py:574-578): consecutive pairs share a transform, DCT(curr_t) IS DCT(prev_{t+1}).
+// So a lane keeps ONE 8x8 block position and marches through a chunk of consecutive frames, carrying
+// the 64 coefficients of the previous frame in registers: one 2-D transform per frame instead of two,
+// every gray plane read once (+ one halo frame per chunk).  Per frame a lane does
+//     64 v_cvt_f32_ubyte  +  16 x 1-D DCT (plain fp32 fma/mul/add)  +  64 fma (energy)  +  128 sub/|add| (L1).
+// A workgroup is ONE wave (64 block positions); the two sums of a frame are reduced over the wave in a fixed
+// DPP order and written as one float2 partial per (frame, wave) - k_dct_finalize2 adds them in double, in
+// index order, so results are bit-reproducible.
+//   grid = (waves per frame / 4, chunks), block = 256 (four independent waves);  planes slot 0 = the frame preceding the batch
+// ---------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) uint64_t *gptr_u64;
+
+template <int ctrl, int row_mask>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    // v + (v moved by the DPP pattern; lanes the pattern does not write contribute 0)
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, row_mask, 0xf, false);
+    return v + __int_as_float(moved);
+}
+// sum over the 64 lanes in a fixed order; the total lands in lane 63
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v = dpp_add<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v); // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v); // row_mirror: every lane of a 16-lane row holds the row's sum
+    v = dpp_add<0x142, 0xa>(v); // row_bcast:15 -> rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v); // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+struct dct_bytes {
+    uint32_t lo[8], hi[8];
+};
+
+// the 8 rows of one 8x8 block of `plane`: rows are 8-byte loads at a wave-uniform row base + a per-lane offset
+// 8-point orthonormal DCT-II for the marching kernel: the butterflies of vqa_math.hpp's dct8 with every constant an
+// instruction LITERAL.  Measured (profiles/round2_valu_calib.json): v_fma/v_mul/v_add_f32 issue at ~2.4-2.9 cycles per
+// wave with VGPR, literal or inline-constant sources but at 4.2-4.5 with an SGPR source, and the compiler keeps the
+// cosine constants of its v_fma_f32 (VOP3: no literals on gfx9) in SGPRs.  v_mul_f32 / v_fmac_f32 are VOP2 and take one.
+#define VQA_FBITS(x) __builtin_bit_cast(int, (float)(x))
+template <int KBITS>
+__device__ __forceinline__ float lit_mul(float x)
+{
+    float d;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "i"(KBITS), "v"(x));
+    return d;
+}
+template <int KBITS>
+__device__ __forceinline__ float lit_fmac(float acc, float x) // acc + K * x
+{
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "i"(KBITS), "v"(x));
+    return acc;
+}
+template <int STRIDE>
+__device__ __forceinline__ void dct8_lit(float *v)
+{
+    constexpr float r8 = 0.35355339059327373f, c1 = 0.49039264020161522f, c2 = 0.46193976625564337f,
+                    c3 = 0.41573480615127262f, c5 = 0.27778511650980114f, c6 = 0.19134171618254492f,
+                    c7 = 0.09754516100806417f;
+    const float x0 = v[0 * STRIDE], x1 = v[1 * STRIDE], x2 = v[2 * STRIDE], x3 = v[3 * STRIDE];
+    const float x4 = v[4 * STRIDE], x5 = v[5 * STRIDE], x6 = v[6 * STRIDE], x7 = v[7 * STRIDE];
+    const float s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
+    const float d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
+    const float t0 = s0 + s3, t1 = s1 + s2, t2 = s0 - s3, t3 = s1 - s2;
+    v[0 * STRIDE] = lit_mul<VQA_FBITS(r8)>(t0 + t1);
+    v[4 * STRIDE] = lit_mul<VQA_FBITS(r8)>(t0 - t1);
+    v[2 * STRIDE] = lit_fmac<VQA_FBITS(c2)>(lit_mul<VQA_FBITS(c6)>(t3), t2);
+    v[6 * STRIDE] = lit_fmac<VQA_FBITS(c6)>(lit_mul<VQA_FBITS(-c2)>(t3), t2);
+    v[1 * STRIDE] = lit_fmac<VQA_FBITS(c1)>(lit_fmac<VQA_FBITS(c3)>(lit_fmac<VQA_FBITS(c5)>(lit_mul<VQA_FBITS(c7)>(d3), d2), d1), d0);
+    v[3 * STRIDE] = lit_fmac<VQA_FBITS(c3)>(lit_fmac<VQA_FBITS(-c7)>(lit_fmac<VQA_FBITS(-c1)>(lit_mul<VQA_FBITS(-c5)>(d3), d2), d1), d0);
+    v[5 * STRIDE] = lit_fmac<VQA_FBITS(c5)>(lit_fmac<VQA_FBITS(-c1)>(lit_fmac<VQA_FBITS(c7)>(lit_mul<VQA_FBITS(c3)>(d3), d2), d1), d0);
+    v[7 * STRIDE] = lit_fmac<VQA_FBITS(c7)>(lit_fmac<VQA_FBITS(-c5)>(lit_fmac<VQA_FBITS(c3)>(lit_mul<VQA_FBITS(-c1)>(d3), d2), d1), d0);
+}
+// 2-D transform with the instruction scheduler fenced every two 1-D transforms: left alone it interleaves all
+// eight rows for ILP and needs ~60 temporaries on top of the 64 coefficients (3 waves/SIMD supply the parallelism)
+__device__ __forceinline__ void dct8x8_fenced(float *v)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        dct8_lit<1>(v + 8 * r);
+        dct8_lit<1>(v + 8 * r + 8);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        dct8_lit<8>(v + c);
+        dct8_lit<8>(v + c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void march_load(dct_bytes &q, const uint8_t *plane, int pitch, uint32_t voff, int by8, int bx8,
+                                           int rows_valid, uint64_t colmask, int h)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint64_t v;
+        if (FULL) {
+            v = *(gptr_u64)(uniform_ptr(plane + (int64_t)r * pitch) + voff);
+        } else { // ragged bottom / right edge: clamp the row, then zero what lies outside (Parseval stays exact)
+            const int y = min(by8 + r, h - 1);
+            v = *(const uint64_t *)(plane + (int64_t)y * pitch + bx8);
+            v = (r < rows_valid) ? (v & colmask) : 0ull;
+        }
+        q.lo[r] = (uint32_t)v;
+        q.hi[r] = (uint32_t)(v >> 32);
+    }
+}
+
+__device__ __forceinline__ void march_unpack(const dct_bytes &q, float *v)
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[8 * r + k] = ub(q.lo[r], k); v[8 * r + 4 + k] = ub(q.hi[r], k); }
+    }
+}
+
+// RAGGED = the plane has a partial last block row/column (w or h not a multiple of 8): per-lane clamped rows and
+// masks cost address registers, so that variant is compiled for 2 waves/SIMD; 1080p/2160p take the other one.
+template <bool ENERGY, bool TEMPORAL, bool RAGGED, bool LOAD_EARLY>
+__global__ __launch_bounds__(256, RAGGED ? 2 : 3) void k_dct8_march(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride,
+                                                      int h, int w, int n, int fch, int nw, int first_has_prev,
+                                                      float2 *__restrict__ partials)
+{
+    // a workgroup is four INDEPENDENT waves (no barrier, no LDS): 256 threads only so that the dispatcher spreads
+    // them one per SIMD (single-wave workgroups measured 2.4x slower: they do not spread evenly over the SIMDs)
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6); // wave index in the frame's block raster
+    const int f0 = blockIdx.y * fch, f1 = min(n, f0 + fch);
+    const int nbx = (w + 7) >> 3, nby = (h + 7) >> 3;
+    const int nblk = nbx * nby;
+    if (wv >= nw) return;
+    int b = wv * 64 + lane;
+    const bool valid = b < nblk;
+    if (!valid) b = nblk - 1;
+    const int by = b / nbx, bx = b - by * nbx;
+    const int by8 = by * 8, bx8 = bx * 8;
+    const int rows_valid = min(8, h - by8), cols_valid = min(8, w - bx8);
+    const uint64_t colmask = cols_valid >= 8 ? ~0ull : ((1ull << (8 * cols_valid)) - 1ull);
+    const uint32_t voff = (uint32_t)by8 * (uint32_t)pitch + (uint32_t)bx8;
+    const float keep = valid ? 1.f : 0.f;
+
+    float A[64], B[64];
+    dct_bytes q;
+    bool have_prev = false;
+    auto load = [&](int slot) {
+        const uint8_t *pl = planes + (int64_t)slot * plane_stride;
+        march_load<!RAGGED>(q, pl, pitch, voff, by8, bx8, rows_valid, colmask, h);
+    };
+    // one frame: bytes in q -> CUR = DCT(frame f); sums against PRV = DCT(frame f-1); next frame's bytes fetched
+    // while the transform runs
+    // The next frame's bytes are requested only after the transform (the byte registers are dead during it: 64 carried +
+    // 64 working coefficients leave no room for them at 3 waves/SIMD); the sums and the other waves cover the latency.
+    auto step = [&](int f, float *CUR, const float *PRV) {
+        march_unpack(q, CUR);
+        __builtin_amdgcn_sched_barrier(0);
+        dct8x8_fenced(CUR);
+        if (LOAD_EARLY) load(min(f + 2, n)); // the chunk's last step re-reads a valid slot instead of branching
+        float e0 = 0.f, e1 = 0.f, t0 = 0.f, t1 = 0.f;
+        if (ENERGY) {
+#pragma unroll
+            for (int i = 0; i < 64; i += 2) { e0 = fmaf(CUR[i], CUR[i], e0); e1 = fmaf(CUR[i + 1], CUR[i + 1], e1); }
+        }
+        if (TEMPORAL && have_prev) {
+#pragma unroll
+            for (int i = 0; i < 64; i += 2) { t0 += fabsf(PRV[i] - CUR[i]); t1 += fabsf(PRV[i + 1] - CUR[i + 1]); }
+        }
+        if (!LOAD_EARLY) { __builtin_amdgcn_sched_barrier(0); load(min(f + 2, n)); }
+        const float e = wave_sum_dpp((e0 + e1) * keep);
+        const float t = wave_sum_dpp((t0 + t1) * keep);
+        if (lane == 63) partials[(int64_t)f * nw + wv] = make_float2(e, t);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (TEMPORAL && (f0 > 0 || first_has_prev)) { // halo: the transform of the frame before the chunk
+        load(f0);
+        march_unpack(q, B);
+        __builtin_amdgcn_sched_barrier(0);
+        dct8x8_fenced(B);
+        have_prev = true;
+    }
+    load(f0 + 1);
+    for (int f = f0; f < f1; f += 2) {
+        step(f, A, B);
+        have_prev = TEMPORAL;
+        if (f + 1 < f1) step(f + 1, B, A);
+    }
+}
+
+// one wave per frame: lane i adds partials i, i+64, ... in double, then a fixed-order shuffle tree (bit-reproducible)
+__global__ __launch_bounds__(64) void k_dct_finalize2(const float2 *__restrict__ partials, int nw, int n,
+                                                      vqa_frame_metrics *__restrict__ res, int write_energy,
+                                                      int write_temporal, int first_has_prev)
+{
+    const int f = blockIdx.x;
+    if (f >= n) return;
+    double e = 0, t = 0;
+    for (int i = threadIdx.x; i < nw; i += 64) { const float2 p = partials[(int64_t)f * nw + i]; e += (double)p.x; t += (double)p.y; }
+    e = wave_sum(e);
+    t = wave_sum(t);
+    if (threadIdx.x == 0) {
+        if (write_energy) res[f].dct_energy = e;
+        if (write_temporal) res[f].temporal_dct_l1 = (f > 0 || first_has_prev) ? t : 0.0;
+    }
+}
+
 // Deterministic second stage: one thread per frame adds the per-block partials
 // in a fixed order and stores them into the result records.
 __global__ void k_dct_finalize(const double *__restrict__ partials, int pb, int n, vqa_frame_metrics *__restrict__ res,
@@ -172,11 +383,21 @@ __global__ void k_dct_finalize(const double *__restrict__ partials, int pb, int 
     if (write_temporal) res[f].temporal_dct_l1 = (f > 0 || first_has_prev) ? t : 0.0;
 }
 
-int dct8_blocks_per_frame(int h, int w)
+static int dct8_blocks_legacy(int h, int w)
 {
     const int nblk = ((w + 7) / 8) * ((h + 7) / 8);
     int pb = (nblk + 256 * 4 - 1) / (256 * 4); // ~4 blocks of pixels per lane
     return pb < 1 ? 1 : (pb > 64 ? 64 : pb);
+}
+
+// 16-byte partial slots per frame the DCT launch needs (sizes the scratch buffer): the marching kernel writes one
+// float2 per wave of 64 block positions, the legacy kernel two doubles per workgroup
+int dct8_blocks_per_frame(int h, int w)
+{
+    const int nblk = ((w + 7) / 8) * ((h + 7) / 8);
+    const int nw = (nblk + 63) / 64;
+    const int legacy = dct8_blocks_legacy(h, w);
+    return (nw + 1) / 2 > legacy ? (nw + 1) / 2 : legacy;
 }
 
 static int dct_variant()
@@ -185,7 +406,7 @@ static int dct_variant()
     if (v < 0) {
         const char *e = getenv("VQA_DCT_VARIANT");
         v = e ? atoi(e) : 0;
-        if (v < 0 || v > 3) v = 0;
+        if (v < 0 || v > 4) v = 0;
     }
     return v;
 }
@@ -206,26 +427,82 @@ static void launch_dct8_v(hipStream_t st, dim3 grid, const uint8_t *planes, int 
                            (int)first_has_prev, partials);
 }
 
+// frames per chunk of the marching kernel: every chunk pays one halo transform, and the grid should fill the
+// chip's wave slots in whole rounds.  cost(k chunks) ~ rounds(k) * (frames per chunk + 1)
+static int dct_march_chunk(int n, int nw)
+{
+    if (const char *e = getenv("VQA_DCT_FCH")) { const int v = atoi(e); if (v > 0) return v < n ? v : n; } // tuning knob
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256, per_cu = 12;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dct8_march<true, true, false, false>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 12;
+        slots = cus * per_cu * 4; // waves
+    }
+    long best_cost = -1;
+    int best = 1;
+    for (int k = 1; k <= n; k++) {
+        const int fch = (n + k - 1) / k, kk = (n + fch - 1) / fch;
+        const long total = (long)kk * nw;
+        const long rounds = (total + slots - 1) / slots;
+        const long cost = rounds * (fch + 1);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && fch < best)) { best_cost = cost; best = fch; }
+        if (fch == 1) break;
+    }
+    return best;
+}
+
 void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
                  bool energy, bool temporal, bool first_has_prev, double *partials, vqa_frame_metrics *res)
 {
     if (n <= 0 || (!energy && !temporal)) return;
-    const int pb = dct8_blocks_per_frame(h, w);
-    dim3 grid(pb, n);
-    if (dct_variant() == 3 && energy && temporal) { // A/B: float2-paired transform
-        hipLaunchKernelGGL(k_dct8_pair, grid, dim3(256), 0, st, planes, pitch, plane_stride, h, w, (int)first_has_prev,
-                           partials);
-        hipLaunchKernelGGL(k_dct_finalize, dim3((n + 63) / 64), dim3(64), 0, st, partials, pb, n, res, 1, 1,
+    if (dct_variant() == 0) { // frame-marching kernel: one transform per frame
+        const int nblk = ((w + 7) / 8) * ((h + 7) / 8), nw = (nblk + 63) / 64;
+        const int fch = dct_march_chunk(n, nw);
+        dim3 grid((nw + 3) / 4, (n + fch - 1) / fch);
+        float2 *p2 = (float2 *)partials;
+        const bool ragged = ((w | h) & 7) != 0;
+        static const bool early = getenv("VQA_DCT_LOAD_EARLY") && atoi(getenv("VQA_DCT_LOAD_EARLY")) != 0; // A/B knob
+#define LAUNCH_MARCH(E, T, R)                                                                                             \
+    do {                                                                                                                  \
+        if (early)                                                                                                        \
+            hipLaunchKernelGGL((k_dct8_march<E, T, R, true>), grid, dim3(256), 0, st, planes, pitch, plane_stride, h, w, n,\
+                               fch, nw, (int)first_has_prev, p2);                                                           \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_dct8_march<E, T, R, false>), grid, dim3(256), 0, st, planes, pitch, plane_stride, h, w, \
+                               n, fch, nw, (int)first_has_prev, p2);                                                        \
+    } while (0)
+        if (energy && temporal) { if (ragged) LAUNCH_MARCH(true, true, true); else LAUNCH_MARCH(true, true, false); }
+        else if (energy) { if (ragged) LAUNCH_MARCH(true, false, true); else LAUNCH_MARCH(true, false, false); }
+        else { if (ragged) LAUNCH_MARCH(false, true, true); else LAUNCH_MARCH(false, true, false); }
+#undef LAUNCH_MARCH
+        hipLaunchKernelGGL(k_dct_finalize2, dim3(n), dim3(64), 0, st, p2, nw, n, res, (int)energy, (int)temporal,
                            (int)first_has_prev);
         return;
     }
-    switch (dct_variant()) { // A/B knob (VQA_DCT_VARIANT): min waves/SIMD 3 (default), 1, 4
-    case 1: launch_dct8_v<1>(st, grid, planes, pitch, plane_stride, h, w, energy, temporal, first_has_prev, partials); break;
-    case 2: launch_dct8_v<4>(st, grid, planes, pitch, plane_stride, h, w, energy, temporal, first_has_prev, partials); break;
-    default: launch_dct8_v<3>(st, grid, planes, pitch, plane_stride, h, w, energy, temporal, first_has_prev, partials); break;
+    // legacy kernels (A/B: VQA_DCT_VARIANT 1, 2, 4 = two transforms per pair at min 1 / 4 / 3 waves per SIMD; 3 = float2-paired)
+    const int pb = dct8_blocks_legacy(h, w);
+    for (int a = 0; a < n; a += 65535) { // frames ride in gridDim.y
+        const int m = n - a < 65535 ? n - a : 65535;
+        dim3 grid(pb, m);
+        const uint8_t *pl = planes + (int64_t)a * plane_stride;
+        double *pp = partials + (int64_t)a * pb * 2;
+        const bool fhp = a > 0 || first_has_prev;
+        if (dct_variant() == 3 && energy && temporal) {
+            hipLaunchKernelGGL(k_dct8_pair, grid, dim3(256), 0, st, pl, pitch, plane_stride, h, w, (int)fhp, pp);
+            hipLaunchKernelGGL(k_dct_finalize, dim3((m + 63) / 64), dim3(64), 0, st, pp, pb, m, res + a, 1, 1, (int)fhp);
+            continue;
+        }
+        switch (dct_variant()) {
+        case 1: launch_dct8_v<1>(st, grid, pl, pitch, plane_stride, h, w, energy, temporal, fhp, pp); break;
+        case 2: launch_dct8_v<4>(st, grid, pl, pitch, plane_stride, h, w, energy, temporal, fhp, pp); break;
+        default: launch_dct8_v<3>(st, grid, pl, pitch, plane_stride, h, w, energy, temporal, fhp, pp); break;
+        }
+        hipLaunchKernelGGL(k_dct_finalize, dim3((m + 63) / 64), dim3(64), 0, st, pp, pb, m, res + a, (int)energy,
+                           (int)temporal, (int)fhp);
     }
-    hipLaunchKernelGGL(k_dct_finalize, dim3((n + 63) / 64), dim3(64), 0, st, partials, pb, n, res, (int)energy,
-                       (int)temporal, (int)first_has_prev);
 }
 
 } // namespace vqa

@@ -3,10 +3,20 @@
 profiles/<tag>_pmc.json: per kernel, mean counter values per launch and the HBM bytes after the
 guide's gfx950 correction (FETCH_SIZE is in KiB and counts 128-B requests as 64 B: double it;
 WRITE_SIZE in KiB is exact).  usage: pmc_summarize.py <tag> <frames_per_launch>"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, subprocess, sys
 tag, frames = sys.argv[1], int(sys.argv[2])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = {"tag": tag, "frames_per_launch": frames, "unit": "bytes per launch",
+csrc = os.path.join(root, "real-time-video-quality-analysis_amd", "csrc")
+# bench.py uses a PMC file only while these hashes match the sources it runs on (roofline.traffic_source)
+hashes = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
+          for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")))}
+sha = os.environ.get("VQA_GIT_SHA", "")
+if not sha:
+    try:
+        sha = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        sha = ""
+out = {"tag": tag, "frames_per_launch": frames, "unit": "bytes per launch", "git_sha": sha or "uncommitted", "source_sha256": hashes,
        "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md §HBM)", "kernels": {}}
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -1,0 +1,115 @@
+"""bench.py's host logic on CPU: the N > 1 rank logic (barrier-fenced timing, max over ranks, the scalar all-reduce,
+the JSON line's shape) rehearsed under gloo world-2 with the engine stubbed (--stub-engine: no kernels, the line says so),
+the fail-loud RCCL rule, the cpu_baseline worker rule and the PMC-traffic staleness check."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, env=None, timeout=240):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run(cmd, cwd=REPO, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_default_workload_is_the_headline_config():
+    # BASELINE.json's metric is "full metric suite @1080p" = configs[2]
+    assert bench.WORKLOADS["c3"]["full"] and (bench.WORKLOADS["c3"]["h"], bench.WORKLOADS["c3"]["w"]) == (1080, 1920)
+    r = _run([sys.executable, "bench.py", "--stub-engine", "--backend", "gloo", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-800:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["id"] == "c3" and line["stub"] is True and line["n_gpus"] == 1
+    assert CONTRACT_KEYS <= set(line)
+
+
+def test_world2_gloo_rank_logic_json_shape():
+    port = _free_port()
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+              "--stub-engine"])
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly ONE JSON line"
+    line = json.loads(lines[0])
+    assert CONTRACT_KEYS <= set(line)
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    cfg = line["config"]
+    assert cfg["collective"] == "gloo scalar all-reduce" and cfg["rccl_ranks"] is None
+    assert cfg["devices"] == [0, 1] and cfg["parallelism"] == "1 stream/GPU x2"
+    # whole-job aggregate: frames of BOTH ranks over the max-over-ranks time
+    frames = cfg["frames_per_step_per_gpu"] * line["steps"] * 2
+    assert abs(line["value"] - frames / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-3 * line["value"]
+
+
+def test_gpus_flag_must_match_world_size():
+    port = _free_port()
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(port), "bench.py", "--gpus", "4", "--backend", "gloo", "--stub-engine"])
+    assert r.returncode != 0
+
+
+def test_stub_engine_refuses_nccl():
+    r = _run([sys.executable, "bench.py", "--stub-engine"])
+    assert r.returncode != 0 and "gloo" in (r.stderr + r.stdout)
+
+
+def test_rccl_failure_is_fatal_unless_rehearsal(monkeypatch):
+    """init_dist: an RCCL bring-up failure exits non-zero (os._exit(3)) unless VQA_BENCH_DEVICE pinned the ranks."""
+    code = (
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=%r, RANK='0', WORLD_SIZE='1')\n"
+        "import bench\n"
+        "td, used, dev, n = bench.init_dist('nccl', 0, 1, 0, %s, False)\n"
+        "print('FELLBACK', used, dev, n)\n"
+    )
+    # no GPU here: the nccl process group cannot come up
+    r = _run([sys.executable, "-c", code % (REPO, str(_free_port()), "False")])
+    assert r.returncode == 3 and "FATAL" in r.stderr and "FELLBACK" not in r.stdout
+    r = _run([sys.executable, "-c", code % (REPO, str(_free_port()), "True")])
+    assert r.returncode == 0 and "FELLBACK gloo cpu None" in r.stdout, r.stderr[-600:]
+
+
+def test_cpu_worker_rule(monkeypatch):
+    monkeypatch.delenv("VQA_CPU_WORKERS", raising=False)
+    assert bench.cpu_workers(16) == (8, False) and bench.cpu_workers(1) == (1, False) and bench.cpu_workers(192) == (96, False)
+    monkeypatch.setenv("VQA_CPU_WORKERS", "5")
+    assert bench.cpu_workers(16) == (5, True)
+    assert bench.visible_cores() >= 1
+
+
+def test_pmc_traffic_goes_null_when_sources_changed(tmp_path, monkeypatch):
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    h = bench.source_hashes()
+    good = {"tag": "round9_c3", "frames_per_launch": 128, "git_sha": "abc1234", "source_sha256": h,
+            "kernels": {"k_ssim_gauss<256, 2, 0>": {"hbm_bytes": 1000}}}
+    (prof / "round9_c3_pmc.json").write_text(json.dumps(good))
+    (prof / "round2_c3_pmc.json").write_text(json.dumps(dict(good, kernels={"k_ssim_gauss<256, 2, 0>": {"hbm_bytes": 1}})))
+    t, src = bench.pmc_traffic("c3", "k_ssim_gauss", 256, True)
+    assert t == 2000 and src == "profiles/round9_c3_pmc.json @ abc1234"  # newest round wins, scaled to this batch
+    stale = dict(good, source_sha256=dict(h, **{"k_quality.hip": "0" * 16}))
+    (prof / "round9_c3_pmc.json").write_text(json.dumps(stale))
+    t, src = bench.pmc_traffic("c3", "k_ssim_gauss", 256, True)
+    assert t is None and src.startswith("stale:")
+    nohash = {k: v for k, v in good.items() if k != "source_sha256"}
+    (prof / "round9_c3_pmc.json").write_text(json.dumps(nohash))
+    assert bench.pmc_traffic("c3", "k_ssim_gauss", 256, True)[0] is None
+    assert bench.pmc_traffic("c3", "k_ssim_gauss", 256, False)[0] is None  # non-default modes have no PMC pass

@@ -109,7 +109,9 @@ def test_dct8_constant_frames_known_answer(engine):
     a = np.full((1, 64, 96, 3), 100, np.uint8)
     b = np.full((64, 96, 3), 97, np.uint8)
     rec = engine.complexity(a, prev0=b, mask=N.M_DCT | N.M_TEMPORAL_DCT, dct_mode=N.DCT_BLOCK8)
-    assert _rel(rec[0]["temporal_dct_l1"], 3 * 64 * 96 / 8) < 1e-6
+    # dct(prev) - dct(curr) in fp32, as the reference computes it (:574-578): the two DC terms (776, 800) round
+    # separately, so the known answer holds to a few fp32 ulps of the DC term, not of the difference
+    assert _rel(rec[0]["temporal_dct_l1"], 3 * 64 * 96 / 8) < 2e-5
     assert _rel(rec[0]["dct_energy"], 100.0 ** 2 * 64 * 96) < 1e-6
     rec = engine.complexity(a, prev0=a[0], mask=N.M_TEMPORAL_DCT, dct_mode=N.DCT_BLOCK8)
     assert rec[0]["temporal_dct_l1"] == 0.0
