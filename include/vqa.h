@@ -113,6 +113,8 @@ typedef struct vqa_frame_metrics {
     uint32_t hyst_steps;         /* diagnostics only (scheduling-dependent): relaxation steps summed over tiles */
     uint32_t orb_keypoints;      /* len(ORB_create().detectAndCompute(gray64)[0])  (:385-389)  */
     uint32_t orb_response;       /* FAST score of that keypoint, 0 when there is none       */
+    uint32_t hyst_overflow;      /* 1 if the Canny hysteresis hit its round bound before the fixpoint:
+                                    edge_count is then a LOWER bound, not the exact count (never seen; asserted 0 in tests) */
     double   flow_mag_mean;      /* VQA_MOTION_FARNEBACK: np.mean(|flow|) (:342-343); else 0 */
 } vqa_frame_metrics;
 

@@ -59,7 +59,7 @@ class VqaFrameMetrics(C.Structure):
                 ("edge_strong", C.c_uint32),
                 ("edge_weak", C.c_uint32),
                 ("has_prev", C.c_uint32),
-                ("hyst_steps", C.c_uint32), ("orb_keypoints", C.c_uint32), ("orb_response", C.c_uint32),
+                ("hyst_steps", C.c_uint32), ("orb_keypoints", C.c_uint32), ("orb_response", C.c_uint32), ("hyst_overflow", C.c_uint32),
                 ("flow_mag_mean", C.c_double)]
 
 

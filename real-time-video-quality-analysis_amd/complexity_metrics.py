@@ -300,8 +300,15 @@ def process_in_batches(frames, process_func, num_workers, batch_size=100, **kwar
             results.extend(_motion_batch(eng, batch))
             continue
         resize = None if kind == "orb" else (kw["resize_width"], kw["resize_height"])
-        arr = np.stack([np.asarray(f) for f in batch])
-        rec = eng.complexity(arr, mask=_MASK[kind], resize=resize)
+        # 2-D (gray) frames are expanded exactly as the per-frame callables do; a chunk whose frames differ in size
+        # cannot be one launch and goes through the per-item map (what the reference's executor.map does anyway)
+        items = [np.asarray(f) for f in batch]
+        items = [np.repeat(f[..., None], 3, axis=2) if f.ndim == 2 else f for f in items]
+        if len({f.shape for f in items}) > 1:
+            call = functools.partial(process_func, **kwargs)
+            results.extend(call(item) for item in batch)
+            continue
+        rec = eng.complexity(np.stack(items), mask=_MASK[kind], resize=resize)
         results.extend(_scalar(kind, r) for r in rec)
     return results
 

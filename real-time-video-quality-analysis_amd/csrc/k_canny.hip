@@ -486,13 +486,14 @@ __global__ __launch_bounds__(256) void k_canny_hyst_list(hyst_args A, const unsi
 __global__ __launch_bounds__(1024) void k_canny_hyst_tail(hyst_args A, unsigned *__restrict__ list0,
                                                          unsigned *__restrict__ cnt0, unsigned *__restrict__ q0,
                                                          unsigned *__restrict__ list1, unsigned *__restrict__ cnt1,
-                                                         unsigned *__restrict__ q1, int first_in)
+                                                         unsigned *__restrict__ q1, int first_in, int max_rounds)
 {
     __shared__ unsigned s_n;
     const unsigned f = blockIdx.x, tpf = (unsigned)(A.tiles_y * A.ww);
     unsigned *lists[2] = {list0, list1}, *cnts[2] = {cnt0, cnt1}, *qs[2] = {q0, q1};
     int in = first_in;
-    for (int round = 0; round < (1 << 16); round++) {
+    bool reached_fixpoint = false;
+    for (int round = 0; round < max_rounds; round++) {
         if (threadIdx.x == 0) {
             s_n = cnts[in][f];
             cnts[in ^ 1][f] = 0; // the list this round builds ...
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(1024) void k_canny_hyst_tail(hyst_args A, unsigned 
         }
         __syncthreads();
         const unsigned n = s_n;
-        if (n == 0) break;
+        if (n == 0) { reached_fixpoint = true; break; }
         A.queued = qs[in ^ 1];
         A.out_list = lists[in ^ 1];
         A.out_count = cnts[in ^ 1];
@@ -522,6 +523,8 @@ __global__ __launch_bounds__(1024) void k_canny_hyst_tail(hyst_args A, unsigned 
         __syncthreads();
         in ^= 1;
     }
+    // the bound exists so the grid always drains; hitting it leaves an UNDER-count, which the record must say
+    if (!reached_fixpoint && threadIdx.x == 0 && cnts[in][f] != 0) A.res[f].hyst_overflow = 1u;
 }
 
 // edge_count so far holds the promotions; add the strong pixels.
@@ -589,9 +592,14 @@ void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const un
                             unsigned *q1, int first_in, vqa_frame_metrics *res)
 {
     if (n <= 0) return;
+    static int max_rounds = 0;
+    if (!max_rounds) { // VQA_HYST_MAX_ROUNDS: test hook for the overflow flag
+        const char *e = getenv("VQA_HYST_MAX_ROUNDS");
+        max_rounds = (e && atoi(e) > 0) ? atoi(e) : (1 << 16);
+    }
     hipLaunchKernelGGL(k_canny_hyst_tail, dim3(n), dim3(1024), 0, st,
                        make_hyst_args(strong, weak, h, w, nullptr, nullptr, nullptr, res), list0, cnt0, q0, list1, cnt1,
-                       q1, first_in);
+                       q1, first_in, max_rounds);
 }
 
 void launch_canny_finish(hipStream_t st, int n, vqa_frame_metrics *res)

@@ -542,7 +542,6 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     if (P.resize_w < 0 || P.resize_h < 0 || ((P.resize_w == 0) != (P.resize_h == 0))) return VQA_ERR_INVALID;
     if (P.dct_mode < VQA_DCT_AUTO || P.dct_mode > VQA_DCT_FULL) return VQA_ERR_INVALID;
     if ((int64_t)h * w > (1ll << 28)) return VQA_ERR_UNSUPPORTED;
-    if (n > 65535) return VQA_ERR_UNSUPPORTED; // frames ride in gridDim.y: split larger batches in the caller
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
 
@@ -553,7 +552,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     const bool want_gh = mask & VQA_M_GRAY_HIST, want_ch = mask & VQA_M_COLOR_HIST, want_dct = mask & VQA_M_DCT;
     const bool want_t = mask & VQA_M_TEMPORAL_DCT, want_e = mask & VQA_M_EDGE, want_m = mask & VQA_M_MOTION;
     const bool want_orb = mask & VQA_M_ORB;
-    const bool has_prev0 = prev0 != nullptr;
+    const bool batch_has_prev0 = prev0 != nullptr;
 
     // ---- bring frames to the device if they are on the host
     const uint8_t *dframes = frames, *dprev = prev0;
@@ -578,7 +577,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             }
         }
         dframes = (const uint8_t *)c->stage_frames.p;
-        if (has_prev0) {
+        if (batch_has_prev0) {
             rc = ensure(c, c->stage_prev, fbytes);
             if (rc) return rc;
             if (padded)
@@ -597,7 +596,19 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     rc = ensure_pinned(c, c->res_host, c->res_host_cap, sizeof(vqa_frame_metrics) * (size_t)n);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->res_dev.p, 0, sizeof(vqa_frame_metrics) * (size_t)n, st));
-    vqa_frame_metrics *res = (vqa_frame_metrics *)c->res_dev.p;
+    vqa_frame_metrics *const res_all = (vqa_frame_metrics *)c->res_dev.p;
+    const uint8_t *const dframes_all = dframes, *const dprev_all = dprev;
+    const int n_all = n;
+
+    // Frames ride in gridDim.y (<= 65535): larger batches are enqueued as consecutive slices on the same stream.  A
+    // slice's "previous frame" is the last frame of the slice before it; scratch planes are reused (stream order).
+    const int SLICE = 32768;
+    for (int a0 = 0; a0 < n_all; a0 += SLICE) {
+    const int n = n_all - a0 < SLICE ? n_all - a0 : SLICE;
+    const uint8_t *dframes = dframes_all + (int64_t)a0 * frame_stride;
+    const uint8_t *dprev = a0 ? dframes_all + (int64_t)(a0 - 1) * frame_stride : dprev_all;
+    const bool has_prev0 = a0 > 0 || batch_has_prev0;
+    vqa_frame_metrics *res = res_all + a0;
 
     // ---- planes
     const bool want_plane = want_gh || want_ch || want_dct || want_t || want_e; // kernels that read the configured plane
@@ -742,6 +753,9 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         prof_scope ps_(c, VQA_K_ORB);
         launch_orb64(st, dframes, n, h, w, frame_stride, row_stride, T64.xofs, T64.xa, T64.yofs, T64.yb, T64.mode, res);
     }
+    c->last_n = n; c->last_has_full = need_full; c->last_has_planes = need_planes; // (debug planes show the last slice)
+    } // slices
+    const bool has_prev0 = batch_has_prev0;
 
     HIPCHK(c, hipGetLastError());
     if (want_gh || want_ch) {
@@ -756,8 +770,8 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     }
     c->pend_c = n;
     c->pend_c_prev0 = has_prev0;
-    c->last_n = n; c->last_h = h; c->last_w = w; c->last_ph = ph; c->last_pw = pw; c->last_pp = pp; c->last_gp = gp;
-    c->last_resized = resized; c->last_has_full = need_full; c->last_has_planes = need_planes;
+    c->last_h = h; c->last_w = w; c->last_ph = ph; c->last_pw = pw; c->last_pp = pp; c->last_gp = gp;
+    c->last_resized = resized;
     return VQA_OK;
 }
 
@@ -783,7 +797,6 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
     if (!c || !ref || !dist || n <= 0 || !planes || n_planes <= 0 || n_planes > 4) return VQA_ERR_INVALID;
     if (mem_kind != VQA_MEM_HOST && mem_kind != VQA_MEM_DEVICE) return VQA_ERR_INVALID;
     if (ssim_mode != VQA_SSIM_GAUSS && ssim_mode != VQA_SSIM_FFMPEG) return VQA_ERR_INVALID;
-    if (n > 65535) return VQA_ERR_UNSUPPORTED; // frames ride in gridDim.y: split larger batches in the caller
     if (c->pend_q) return VQA_ERR_STATE;
     int64_t span = 0;
     int maxblocks = 1;
@@ -819,12 +832,16 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
     if (rc) return rc;
     rc = ensure_pinned(c, c->qres_host, c->qres_host_cap, sizeof(vqa_plane_metrics) * nent);
     if (rc) return rc;
-    rc = ensure(c, c->qpartials, sizeof(double) * (size_t)maxblocks * n * n_planes);
+    const int QSLICE = 32768; // frames ride in gridDim.y (<= 65535): larger batches go out as consecutive slices
+    const int nslice = n < QSLICE ? n : QSLICE;
+    rc = ensure(c, c->qpartials, sizeof(double) * (size_t)maxblocks * nslice * n_planes);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->qres_dev.p, 0, sizeof(vqa_plane_metrics) * nent, st));
-    vqa_plane_metrics *res = (vqa_plane_metrics *)c->qres_dev.p;
-    const int64_t pstride = (int64_t)maxblocks * n;
-    {
+    const int64_t pstride = (int64_t)maxblocks * nslice;
+    for (int a0 = 0; a0 < n; a0 += QSLICE) {
+        const int m = n - a0 < QSLICE ? n - a0 : QSLICE;
+        vqa_plane_metrics *res = (vqa_plane_metrics *)c->qres_dev.p + (size_t)a0 * n_planes;
+        const uint8_t *sref = dref + (int64_t)a0 * ref_fs, *sdist = ddist + (int64_t)a0 * dist_fs;
         // planes of identical geometry (B,G,R of packed BGR; U,V of 4:2:0) go out as one group
         bool done[4] = {false, false, false, false};
         for (int p = 0; p < n_planes; p++) {
@@ -839,10 +856,10 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
             }
             prof_scope ps_(c, ssim_mode == VQA_SSIM_GAUSS ? VQA_K_SSIM_GAUSS : VQA_K_SSIM_FFMPEG);
             if (ssim_mode == VQA_SSIM_GAUSS)
-                launch_quality_gauss(st, dref, ddist, n, ref_fs, dist_fs, planes, idx, cnt, n_planes,
+                launch_quality_gauss(st, sref, sdist, m, ref_fs, dist_fs, planes, idx, cnt, n_planes,
                                      (double *)c->qpartials.p, pstride, res);
             else
-                launch_quality_ffmpeg(st, dref, ddist, n, ref_fs, dist_fs, planes, idx, cnt, n_planes,
+                launch_quality_ffmpeg(st, sref, sdist, m, ref_fs, dist_fs, planes, idx, cnt, n_planes,
                                       (double *)c->qpartials.p, pstride, res);
         }
     }

@@ -24,7 +24,8 @@ FRAME_DTYPE = np.dtype([
     ("edge_strong", np.uint32),
     ("edge_weak", np.uint32),
     ("has_prev", np.uint32),
-    ("hyst_steps", np.uint32), ("orb_keypoints", np.uint32), ("orb_response", np.uint32), ("flow_mag_mean", np.float64),
+    ("hyst_steps", np.uint32), ("orb_keypoints", np.uint32), ("orb_response", np.uint32), ("hyst_overflow", np.uint32),
+    ("flow_mag_mean", np.float64),
 ], align=True)
 PLANE_DTYPE = np.dtype([("sse", np.uint64), ("ssim", np.float64)], align=True)
 assert FRAME_DTYPE.itemsize == C.sizeof(N.VqaFrameMetrics), (FRAME_DTYPE.itemsize, C.sizeof(N.VqaFrameMetrics))
@@ -175,8 +176,8 @@ class Engine:
             return (frames.ptr, pp, N.VQA_MEM_DEVICE, frames.n, frames.h, frames.w, frames.frame_stride,
                     frames.row_stride, (frames, prev0))
         arr = np.asarray(frames)
-        if arr.dtype != np.uint8:
-            arr = arr.astype(np.uint8)
+        if arr.dtype != np.uint8:  # a silent cast would turn float frames in 0..1 into all-zero planes
+            raise ValueError("frames must be uint8 (got %s): decoded 8-bit BGR frames, as cv2.VideoCapture.read yields" % arr.dtype)
         if arr.ndim == 3:
             arr = arr[None]
         if arr.ndim != 4 or arr.shape[3] != 3:
@@ -191,7 +192,9 @@ class Engine:
         keep = [arr]
         pp = None
         if prev0 is not None:
-            p0 = np.asarray(prev0, dtype=np.uint8)
+            p0 = np.asarray(prev0)
+            if p0.dtype != np.uint8:
+                raise ValueError("prev0 must be uint8 (got %s)" % p0.dtype)
             if p0.shape != arr.shape[1:]:
                 raise ValueError("prev0 must have the frames' geometry")
             if not (p0.strides[1:] == (3, 1) and (h_ == 1 or p0.strides[0] == rstride)):

@@ -61,6 +61,25 @@ def test_process_in_batches_known_kernels_and_order():
     assert got == [pl.process_frame_complexity(pr) for pr in unchained]
 
 
+def test_process_in_batches_gray_and_mixed_size_items():
+    """The batched path takes what the per-frame callables (and the reference's per-item executor.map, :146-147) take:
+    2-D gray frames, and chunks whose frames differ in size; anything but uint8 is rejected, not silently cast."""
+    from oracle import c_oracle as co
+    from rtvqa_amd import complexity_metrics as cm
+    fr = list(_clip(5, 72, 96, seed=4))
+    gray = [co.bgr2gray(f) for f in fr]
+    got = cm.process_in_batches(gray, cm.process_edge_frame, 2, batch_size=3, resize_width=48, resize_height=40)
+    assert got == [cm.process_edge_frame(g, 48, 40) for g in gray]
+    assert got == [pl.process_edge_frame(np.repeat(g[..., None], 3, 2), 48, 40) for g in gray]
+    mixed = [fr[0], fr[1][:60, :80], gray[2], fr[3][:, :50], fr[4]]
+    got = cm.process_in_batches(mixed, cm.process_histogram_frame, 2, batch_size=4, resize_width=32, resize_height=32)
+    assert got == [cm.process_histogram_frame(np.ascontiguousarray(m), 32, 32) for m in mixed]
+    with pytest.raises(ValueError):
+        cm.process_in_batches([f.astype(np.float32) / 255 for f in fr], cm.process_dct_frame, 2, resize_width=32, resize_height=32)
+    with pytest.raises(ValueError):
+        cm.process_dct_frame(fr[0].astype(np.float32) / 255, 32, 32)
+
+
 @pytest.mark.parametrize("interval,resize,n", [(10, (64, 64), 45), (1, (160, 120), 6), (10, (64, 64), 15)])
 def test_calculate_average_scene_complexity(interval, resize, n):
     """config.json's configuration (64x64, interval 10) and a native-size interval-1 run."""

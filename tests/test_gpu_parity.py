@@ -3,6 +3,8 @@
 Bit-exact for histogram bins, gray/resized planes, edge counts/maps, SAD sums and SSE;
 1e-4 relative (the tolerance BASELINE.json's north_star states) for DCT / SSIM floats.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -17,6 +19,9 @@ RTOL = 1e-4  # north_star: "within 1e-4 relative for DCT/SSIM/PSNR floats"
 
 def _rng(seed):
     return np.random.default_rng(seed)
+
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _frames(kind, n, h, w, seed=0):
@@ -36,6 +41,19 @@ def _stable(rec):
 
 def _rel(a, b):
     return abs(a - b) / max(abs(b), 1e-30)
+
+
+@pytest.fixture(autouse=True)
+def _no_hysteresis_overflow(engine, monkeypatch):
+    """Every complexity batch of every test: the Canny fixpoint was reached (hyst_overflow is the record's flag for
+    "the bounded tail stopped early, edge_count is an under-count")."""
+    wait = engine.complexity_wait
+
+    def checked():
+        rec = wait()
+        assert not rec["hyst_overflow"].any(), "Canny hysteresis stopped at its round bound"
+        return rec
+    monkeypatch.setattr(engine, "complexity_wait", checked)
 
 
 # ---------------------------------------------------------------------------
@@ -115,6 +133,28 @@ def test_dct8_constant_frames_known_answer(engine):
     assert _rel(rec[0]["dct_energy"], 100.0 ** 2 * 64 * 96) < 1e-6
     rec = engine.complexity(a, prev0=a[0], mask=N.M_TEMPORAL_DCT, dct_mode=N.DCT_BLOCK8)
     assert rec[0]["temporal_dct_l1"] == 0.0
+
+
+def test_dct_full_frame_1080p_native_vs_scipy(engine):
+    """N1: the reference's full-frame temporal DCT at NATIVE 1080x1920 (complexity_metrics.py:363-364, :574-579) on the
+    fp32 MFMA path - 128x128 tiles with a ragged edge (1080 % 128 != 0), the prefetch tail and the |.| reduction.
+    Checker: scipy.fft.dctn(norm="ortho") in float64 (the C oracle's O(N^3) loop is too slow at this size)."""
+    import scipy.fft
+    from rtvqa_amd import _native as N
+    h, w = 1080, 1920
+    fr = _frames("natural", 3, h, w, seed=23)
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_DCT | N.M_TEMPORAL_DCT, dct_mode=N.DCT_FULL)
+    coef = [scipy.fft.dctn(co.bgr2gray(f).astype(np.float64), norm="ortho") for f in fr]
+    for i in range(2):
+        e = float((coef[i + 1] ** 2).sum())
+        l1 = float(np.abs(coef[i] - coef[i + 1]).sum())
+        assert _rel(rec[i]["dct_energy"], e) < RTOL, (rec[i]["dct_energy"], e)
+        assert _rel(rec[i]["dct_energy"], float(rec[i]["sum_gray2"])) < RTOL  # Parseval
+        assert _rel(rec[i]["temporal_dct_l1"], l1) < RTOL, (rec[i]["temporal_dct_l1"], l1)
+    # a constant brightness step: full-frame L1 = |delta| * sqrt(W H) exactly (only the DC term moves)
+    a = np.full((1, h, w, 3), 120, np.uint8)
+    rec = engine.complexity(a, prev0=np.full((h, w, 3), 117, np.uint8), mask=N.M_TEMPORAL_DCT, dct_mode=N.DCT_FULL)
+    assert _rel(rec[0]["temporal_dct_l1"], 3 * np.sqrt(h * w)) < RTOL
 
 
 @pytest.mark.parametrize("h,w,rw,rh", [(270, 480, 64, 64), (64, 64, 64, 64), (90, 120, 40, 24),
@@ -559,8 +599,64 @@ def test_many_small_frames_one_batch(engine):
     for i in (0, 1499, n - 1):
         a, b = np.ascontiguousarray(fr[i, ..., 1]), np.ascontiguousarray(fr[i + 1, ..., 1])
         assert int(q[i, 0]["sse"]) == co.sse_plane(a, b) and _rel(q[i, 0]["ssim"], co.ssim_gauss(a, b)) < RTOL
-    with pytest.raises(N.VqaError):
-        engine.complexity(np.zeros((65536, 8, 8, 3), np.uint8), mask=N.M_GRAY_HIST)  # documented limit
+
+
+def test_more_than_65535_frames_in_one_submit(engine):
+    """Frames ride in gridDim.y (<= 65535); the C ABI slices larger batches internally, carrying the previous frame
+    across the slice seam (32768 | 32769)."""
+    from rtvqa_amd import _native as N
+    from rtvqa_amd.engine import gray_planes
+    n, h, w = 70000, 16, 24
+    fr = _rng(81).integers(0, 256, (n + 1, h, w, 3), dtype=np.uint8)
+    fr[::5, 4:12, 6:18] = 255
+    rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8, canny=(30, 90))
+    assert rec.shape == (n,) and (rec["has_prev"] == 1).all()
+    for i in [0, 1, 32766, 32767, 32768, 32769, 65534, 65535, 65536, n - 1]:
+        g, gp = co.bgr2gray(fr[i + 1]), co.bgr2gray(fr[i])
+        assert (rec[i]["hist_gray"] == co.hist_u8(g)).all(), i
+        assert int(rec[i]["edge_count"]) == co.canny(g, 30, 90)[0], i
+        nb, sad, hist = co.block_sad(gp, g, 7)
+        assert (int(rec[i]["sad_sum"]), int(rec[i]["sad_blocks"])) == (sad, nb) and (rec[i]["mv_d2_hist"] == hist).all(), i
+        e, l1, _ = co.dct8x8(gp, g)
+        assert _rel(rec[i]["dct_energy"], e) < RTOL and _rel(rec[i]["temporal_dct_l1"], l1) < RTOL, i
+    q = engine.quality(fr[:-1, ..., 1], fr[1:, ..., 1], gray_planes(h, w), N.SSIM_GAUSS)
+    assert q.shape[0] == n
+    for i in (0, 32767, 32768, 65536, n - 1):
+        a, b = np.ascontiguousarray(fr[i, ..., 1]), np.ascontiguousarray(fr[i + 1, ..., 1])
+        assert int(q[i, 0]["sse"]) == co.sse_plane(a, b) and _rel(q[i, 0]["ssim"], co.ssim_gauss(a, b)) < RTOL, i
+    q = engine.quality(fr[:-1, ..., 1], fr[1:, ..., 1], gray_planes(h, w), N.SSIM_FFMPEG)
+    for i in (0, 32768, n - 1):
+        a, b = np.ascontiguousarray(fr[i, ..., 1]), np.ascontiguousarray(fr[i + 1, ..., 1])
+        assert int(q[i, 0]["sse"]) == co.sse_plane(a, b) and _rel(q[i, 0]["ssim"], co.ssim_ffmpeg(a, b)) < RTOL, i
+
+
+def test_hysteresis_overflow_is_flagged():
+    """The tail's round bound exists so the grid always drains; hitting it must SAY so (hyst_overflow = 1) instead of
+    returning a silent under-count.  Forced here with VQA_HYST_MAX_ROUNDS=1 (read once per process => subprocess)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import rtvqa_amd\n"
+        "from rtvqa_amd import _native as N\n"
+        "r = np.full((80, 4000), 20, np.uint8); r[40, :] = 50; r[40, 5] = 255\n"
+        "fr = np.repeat(r[None, :, :, None], 3, 3)\n"
+        "eng = rtvqa_amd.Engine(0)\n"
+        "rec = eng.complexity(fr, mask=N.M_EDGE)\n"
+        "print('RESULT', int(rec[0]['hyst_overflow']), int(rec[0]['edge_count']))\n" % REPO_ROOT
+    )
+    out = {}
+    for rounds in ("1", ""):
+        env = dict(os.environ)
+        env.pop("VQA_HYST_MAX_ROUNDS", None)
+        if rounds:
+            env["VQA_HYST_MAX_ROUNDS"] = rounds
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-800:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+        out[rounds] = (int(line[1]), int(line[2]))
+    assert out[""][0] == 0 and out["1"][0] == 1, out
+    assert out["1"][1] < out[""][1], out  # the bounded run is an under-count, and says so
 
 
 def test_region_of_interest_padded_rows(engine):
