@@ -630,6 +630,31 @@ def test_more_than_65535_frames_in_one_submit(engine):
         assert int(q[i, 0]["sse"]) == co.sse_plane(a, b) and _rel(q[i, 0]["ssim"], co.ssim_ffmpeg(a, b)) < RTOL, i
 
 
+def test_pruned_block_sad_variant_is_bit_identical():
+    """VQA_SAD_VARIANT=2 (successive-elimination search, k_block_sad_sea) must return the exhaustive winner: sad_sum
+    and the d^2 histogram bit for bit, on natural, noise, ragged and tiny planes and for every search range."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import rtvqa_amd\n"
+        "from rtvqa_amd import _native as N, synth\n"
+        "from oracle import c_oracle as co\n"
+        "eng = rtvqa_amd.Engine(0)\n"
+        "cases = [('natural', 270, 480, 7), ('noise', 97, 131, 7), ('natural', 64, 200, 3), ('noise', 33, 47, 0), ('natural', 1080, 1920, 7), ('noise', 16, 16, 5)]\n"
+        "for kind, h, w, R in cases:\n"
+        "    fr = synth.s_natural(3, h, w, seed=5) if kind == 'natural' else synth.s_noise(3, h, w, seed=5)\n"
+        "    rec = eng.complexity(fr[1:], prev0=fr[0], mask=N.M_MOTION, sad_range=R)\n"
+        "    for i in range(2):\n"
+        "        nb, sad, hist = co.block_sad(co.bgr2gray(fr[i]), co.bgr2gray(fr[i + 1]), R)\n"
+        "        assert int(rec[i]['sad_blocks']) == nb and int(rec[i]['sad_sum']) == sad and (rec[i]['mv_d2_hist'] == hist).all(), (kind, h, w, R, i)\n"
+        "print('PRUNED-OK')\n" % REPO_ROOT
+    )
+    env = dict(os.environ, VQA_SAD_VARIANT="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=REPO_ROOT)
+    assert r.returncode == 0 and "PRUNED-OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
+
+
 def test_hysteresis_overflow_is_flagged():
     """The tail's round bound exists so the grid always drains; hitting it must SAY so (hyst_overflow = 1) instead of
     returning a silent under-count.  Forced here with VQA_HYST_MAX_ROUNDS=1 (read once per process => subprocess)."""
