@@ -64,6 +64,23 @@ int main(void)
         bad += !(pm[i * 3].ssim > 0.99 && pm[i * 3].ssim < 1.0);
         bad += fm[i].has_prev != 1u;
     }
+    /* the path's one collective: pooled scalars summed over the communicator's devices (here: this one device,
+     * so the sum is the input).  A multi-GPU host passes one ctx per device, or joins by rank (vqa_comm_create_rank). */
+    {
+        vqa_comm *comm = NULL;
+        double pooled[2] = {fm[n - 1].dct_energy, (double)n};
+        const double want0 = pooled[0];
+        int rc = vqa_comm_create(&ctx, 1, &comm);
+        if (rc == VQA_ERR_UNSUPPORTED) {
+            puts("RCCL not installed: collective skipped");
+        } else {
+            if (rc != VQA_OK) { fprintf(stderr, "vqa_comm_create -> %s\n", vqa_strerror(rc)); return 2; }
+            CHECK(vqa_allreduce(comm, pooled, 2));
+            printf("all-reduce over %d device(s): dct_energy %.6g frames %.0f\n", vqa_comm_size(comm), pooled[0], pooled[1]);
+            bad += pooled[0] != want0 || pooled[1] != (double)n;
+            CHECK(vqa_comm_destroy(comm));
+        }
+    }
     free(fm);
     CHECK(vqa_free_pinned(ctx, ref));
     CHECK(vqa_free_pinned(ctx, dist));

@@ -39,7 +39,7 @@ extern "C" {
 #define VQA_API
 #endif
 
-#define VQA_ABI_VERSION 3
+#define VQA_ABI_VERSION 4
 
 typedef enum vqa_status {
     VQA_OK = 0,
@@ -162,8 +162,9 @@ VQA_API void *vqa_stream(vqa_ctx *ctx);
  * inside larger frames; only the 3*w bytes of each row are ever read).
  * prev0: the frame preceding frames[0] (same geometry, row_stride and
  * mem_kind) or NULL; frame i's "previous" is frame i-1.
- * Asynchronous: returns once the work is enqueued.  Limits: n <= 65535 frames
- * per call, h*w <= 2^28 pixels (VQA_ERR_UNSUPPORTED beyond).                  */
+ * Asynchronous: returns once the work is enqueued.  Limits: h*w <= 2^28 pixels
+ * (VQA_ERR_UNSUPPORTED beyond); n is bounded by memory only (batches above 32768
+ * frames are enqueued as consecutive slices internally).                       */
 VQA_API int vqa_complexity_submit(vqa_ctx *ctx, const uint8_t *frames, const uint8_t *prev0, int mem_kind,
                           int n, int h, int w, int64_t frame_stride, int64_t row_stride,
                           uint32_t metric_mask, const vqa_params *params);
@@ -199,6 +200,27 @@ enum vqa_kernel_id {
 VQA_API int vqa_profile_enable(vqa_ctx *ctx, int on);
 VQA_API int vqa_profile_read(vqa_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches, int reset);
 VQA_API const char *vqa_kernel_name(int kernel_id);
+
+/* ---- the path's one collective: SUM all-reduce of pooled scalars (RCCL over xGMI) ---
+ * The reference has no communication layer (its parallelism is a process pool over
+ * frames, complexity_metrics.py:143-147); frame batches shard one stream per GPU and
+ * only a handful of pooled float64 scalars ever cross devices.
+ * RCCL is loaded on first use (dlopen librccl.so.1): VQA_ERR_UNSUPPORTED without it.   */
+typedef struct vqa_comm vqa_comm;
+#define VQA_COMM_ID_BYTES 128
+/* single process, several devices: one ctx per device (ncclCommInitAll)                */
+VQA_API int vqa_comm_create(vqa_ctx *const *ctxs, int n_ctx, vqa_comm **out);
+/* one process per device: rank 0 makes an id, the host program ships its
+ * VQA_COMM_ID_BYTES bytes to the other ranks by its own means, every rank joins        */
+VQA_API int vqa_comm_unique_id(void *id, size_t id_bytes);
+VQA_API int vqa_comm_create_rank(vqa_ctx *ctx, const void *id, size_t id_bytes, int n_ranks, int rank, vqa_comm **out);
+VQA_API int vqa_comm_destroy(vqa_comm *comm);
+VQA_API int vqa_comm_size(const vqa_comm *comm);           /* ranks in the communicator */
+VQA_API const char *vqa_comm_last_error(const vqa_comm *comm);
+/* In place: vals is [local contexts][count] doubles, row i belongs to the i-th local
+ * context (one row with vqa_comm_create_rank); on return every row holds the sum over
+ * ALL ranks.  count <= 64.  Blocking; runs on the contexts' streams.                   */
+VQA_API int vqa_allreduce(vqa_comm *comm, double *vals, int count);
 
 /* ---- introspection for tests (device-side intermediates) ------------------ */
 /* Copies intermediate planes of the LAST complexity batch to host memory:

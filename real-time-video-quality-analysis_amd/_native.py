@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvqa_hip.so")
 
-VQA_ABI_VERSION = 3
+VQA_ABI_VERSION = 4
 
 VQA_OK = 0
 VQA_ERR_INVALID = -1
@@ -101,6 +101,13 @@ SIGNATURES = {
     "vqa_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "vqa_kernel_name": (C.c_char_p, [C.c_int]),
     "vqa_debug_read_plane": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]),
+    "vqa_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "vqa_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "vqa_comm_create_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "vqa_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vqa_comm_size": (C.c_int, [C.c_void_p]),
+    "vqa_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "vqa_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
 }
 
 _lib = None

@@ -523,6 +523,9 @@ int vqa_sync(vqa_ctx *c)
     return VQA_OK;
 }
 void *vqa_stream(vqa_ctx *c) { return c ? (void *)c->stream : nullptr; }
+// internal accessors for vqa_comm.hip (not part of the ABI: hidden visibility)
+extern "C" __attribute__((visibility("hidden"))) int vqa_ctx_device_(const vqa_ctx *c) { return c->device; }
+extern "C" __attribute__((visibility("hidden"))) void *vqa_ctx_stream_(const vqa_ctx *c) { return (void *)c->stream; }
 
 // ---------------------------------------------------------------------------
 int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev0, int mem_kind, int n, int h, int w,

@@ -136,3 +136,51 @@ def test_plain_c_host_runs_on_the_gpu(tmp_path):
     N.load()
     r = subprocess.run([_build_demo(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "vqa_demo ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_collective_entry_points_reject_bad_arguments():
+    """vqa_comm_* / vqa_allreduce argument checks need no device (and never load RCCL)."""
+    from rtvqa_amd import _native as N
+    lib = N.load()
+    out = C.c_void_p()
+    assert lib.vqa_comm_create(None, 1, C.byref(out)) == N.VQA_ERR_INVALID
+    assert lib.vqa_comm_create_rank(None, None, 128, 2, 0, C.byref(out)) == N.VQA_ERR_INVALID
+    assert lib.vqa_comm_unique_id(None, 128) == N.VQA_ERR_INVALID
+    buf = (C.c_char * 64)()
+    assert lib.vqa_comm_unique_id(buf, 64) == N.VQA_ERR_INVALID  # an id needs VQA_COMM_ID_BYTES = 128 bytes
+    assert lib.vqa_allreduce(None, (C.c_double * 2)(), 2) == N.VQA_ERR_INVALID
+    assert lib.vqa_comm_destroy(None) == N.VQA_ERR_INVALID
+
+
+@pytest.mark.gpu
+def test_allreduce_over_rccl_single_device():
+    """The C-ABI collective on the one GPU of the test box: both ways of building a communicator (all local devices /
+    join by rank) and a SUM all-reduce of pooled float64 scalars; more than 64 values or a duplicate device is refused."""
+    from rtvqa_amd import _native as N
+    lib = N.load()
+    ctx = C.c_void_p()
+    N.check(lib.vqa_create(0, C.byref(ctx)), "vqa_create")
+    try:
+        comm = C.c_void_p()
+        arr = (C.c_void_p * 1)(ctx)
+        st = lib.vqa_comm_create(arr, 1, C.byref(comm))
+        if st == N.VQA_ERR_UNSUPPORTED:
+            pytest.skip("librccl.so.1 is not installed")
+        N.check(st, "vqa_comm_create", ctx)
+        assert lib.vqa_comm_size(comm) == 1
+        vals = (C.c_double * 7)(*[1.5, -2.25, 3e300, 4.0, 5.0, 6.0, 2257755.44])
+        N.check(lib.vqa_allreduce(comm, vals, 7), "vqa_allreduce")
+        assert list(vals) == [1.5, -2.25, 3e300, 4.0, 5.0, 6.0, 2257755.44]
+        assert lib.vqa_allreduce(comm, (C.c_double * 65)(), 65) == N.VQA_ERR_INVALID
+        N.check(lib.vqa_comm_destroy(comm), "vqa_comm_destroy")
+        two = (C.c_void_p * 2)(ctx, ctx)
+        assert lib.vqa_comm_create(two, 2, C.byref(comm)) == N.VQA_ERR_INVALID  # one ctx per device
+        uid = (C.c_char * 128)()
+        N.check(lib.vqa_comm_unique_id(uid, 128), "vqa_comm_unique_id")
+        N.check(lib.vqa_comm_create_rank(ctx, uid, 128, 1, 0, C.byref(comm)), "vqa_comm_create_rank")
+        one = (C.c_double * 2)(7.0, 9.0)
+        N.check(lib.vqa_allreduce(comm, one, 2), "vqa_allreduce")
+        assert list(one) == [7.0, 9.0]
+        N.check(lib.vqa_comm_destroy(comm), "vqa_comm_destroy")
+    finally:
+        lib.vqa_destroy(ctx)
