@@ -244,7 +244,8 @@ def end_to_end(rtvqa_amd, N, device, eng, ref_pin, dist_pin, h, w, full, mask, p
     return dict(fps=round(Be * steps / dt, 1), h2d_GBps=round(gb / dt, 2), pinned=True,
                 overlap="2 contexts ping-ponged: H2D of batch i+1 overlaps the kernels of batch i",
                 frames_per_step=Be, steps=steps,
-                note="PCIe Gen5 x16 bound (12.4 MB per 1080p BGR frame pair); measured after the timed region, never `value`")
+                note="PCIe Gen5 x16 bound (%.1f MB per %dx%d BGR frame pair); measured after the timed region, never `value`"
+                     % (2 * fb / 1e6, w, h))
 
 
 # ---------------------------------------------------------------------------

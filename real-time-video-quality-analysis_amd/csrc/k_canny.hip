@@ -361,8 +361,13 @@ __device__ __forceinline__ row64 dil3(row64 s, uint32_t l, uint32_t r)
     return row64{s.lo | sl.lo | sr.lo | l, s.hi | sl.hi | sr.hi | (r << 31)};
 }
 
-__device__ __forceinline__ row64 shfl_up_row(row64 v) { return row64{(uint32_t)__shfl_up((int)v.lo, 1, 64), (uint32_t)__shfl_up((int)v.hi, 1, 64)}; }
-__device__ __forceinline__ row64 shfl_dn_row(row64 v) { return row64{(uint32_t)__shfl_down((int)v.lo, 1, 64), (uint32_t)__shfl_down((int)v.hi, 1, 64)}; }
+// lane i <- lane i-1 (lane 0 keeps its own) / lane i <- lane i+1 (lane 63 keeps its own): whole-wave DPP shifts
+// (wave_shr:1 / wave_shl:1, one vector-ALU instruction) instead of ds_bpermute round trips through the LDS pipe -
+// the relaxation loop is a dependent chain, so the shuffle latency is on its critical path
+__device__ __forceinline__ uint32_t lane_up32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t lane_dn32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ row64 shfl_up_row(row64 v) { return row64{lane_up32(v.lo), lane_up32(v.hi)}; }
+__device__ __forceinline__ row64 shfl_dn_row(row64 v) { return row64{lane_dn32(v.lo), lane_dn32(v.hi)}; }
 
 struct hyst_args {
     u64 *strong;
@@ -406,8 +411,8 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
         }
     }
     const uint32_t hl32 = (uint32_t)hl, hr32 = (uint32_t)hr;
-    uint32_t up_l = (uint32_t)__shfl_up((int)hl32, 1, 64), up_r = (uint32_t)__shfl_up((int)hr32, 1, 64);
-    uint32_t dn_l = (uint32_t)__shfl_down((int)hl32, 1, 64), dn_r = (uint32_t)__shfl_down((int)hr32, 1, 64);
+    uint32_t up_l = lane_up32(hl32), up_r = lane_up32(hr32);
+    uint32_t dn_l = lane_dn32(hl32), dn_r = lane_dn32(hr32);
     if (lane == 0) { up_l = (uint32_t)el; up_r = (uint32_t)er; }
     if (lane == 63) { dn_l = (uint32_t)el; dn_r = (uint32_t)er; }
     const row64 wr = to_row(w), F = to_row(s0 | w), esr = to_row(es);
@@ -433,8 +438,12 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     // (Candidate bits may be stale by one promotion: stale edge bits only ever make this test MORE
     // inclusive, never less, because edges only grow.)
     const u64 pb0 = promoted & 1ull, pb63 = promoted >> 63;
-    u64 n0 = pb0 | (u64)__shfl_up((int)pb0, 1, 64) * (lane > 0) | (u64)__shfl_down((int)pb0, 1, 64) * (lane < 63);
-    u64 n63 = pb63 | (u64)__shfl_up((int)pb63, 1, 64) * (lane > 0) | (u64)__shfl_down((int)pb63, 1, 64) * (lane < 63);
+    // (DPP moves read their source lanes under the CURRENT exec mask: shift first, with every lane active, select after)
+    const uint32_t p0 = (uint32_t)pb0, p63 = (uint32_t)pb63;
+    const uint32_t p0u = lane_up32(p0), p0d = lane_dn32(p0), p63u = lane_up32(p63), p63d = lane_dn32(p63);
+    const uint32_t m_up = lane > 0 ? ~0u : 0u, m_dn = lane < 63 ? ~0u : 0u;
+    const u64 n0 = pb0 | (u64)(p0u & m_up) | (u64)(p0d & m_dn);
+    const u64 n63 = pb63 | (u64)(p63u & m_up) | (u64)(p63d & m_dn);
     const bool L = __any((cl & n0) != 0), R = __any((cr & n63) != 0);
     const u64 pd = promoted | (promoted << 1) | (promoted >> 1); // promoted row, dilated along x
     const bool Uf = __any(lane == 0 && (ecs & pd) != 0), Df = __any(lane == 63 && (ecs & pd) != 0);

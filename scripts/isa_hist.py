@@ -37,7 +37,8 @@ def load_costs(waves):
     cost = {}
     for name, per_w in ops.items():
         base = name.split()[0].split("(")[0]
-        if "dependent" in name or "vcc written" in name or "+" in name:
+        if "dependent" in name or "vcc written" in name or "+" in name or "(literal" in name or "(inline" in name \
+                or "modifier" in name or "(sgpr src)" in name and base != "v_fma_f32":
             continue
         if base == "v_cndmask_b32" and "sgpr" not in name:
             continue  # VCC not freshly written by the VALU: a 19-cycle artefact compiled code does not show
@@ -82,15 +83,16 @@ def price(op, operands, cost, unknown):
     for s in suffixes:
         if op.endswith(s):
             op = op[: -len(s)]
-    if dpp:
-        return cost["v_mov_b32"] if False else cost.get("v_mov_b32 dpp", cost["v_pk_add_u16"])
+    if dpp:  # every DPP form issues at the half-rate class (probed: v_mov_b32 dpp row_shr:1)
+        return cost.get("v_mov_b32 dpp", cost["v_pk_add_u16"])
     if CMP_RE.match(op) or op.startswith("v_cmp"):
         return cost["v_cmp_gt_u32"]
     if op == "v_cndmask_b32":
         return cost["v_cndmask_b32"] if "v_cndmask_b32" in cost else cost["v_perm_b32"]
     base = ALIAS.get(op, op)
     # a scalar-register (or literal) source on a plain fp32 FMA costs the slow form (calibrated)
-    if base in ("v_fma_f32",) and re.search(r"(^|[ ,])(s\d+|s\[\d+:\d+\]|0x[0-9a-f]+)(,|$)", operands):
+    if base in ("v_fma_f32", "v_fmac_f32", "v_add_f32", "v_mul_f32", "v_add_u32", "v_and_b32", "v_or_b32", "v_xor_b32") and re.search(r"(^|[ ,])(s\d+|s\[\d+:\d+\]|vcc_lo|vcc_hi)(,|$)", operands):
+        # an SGPR source halves the rate of the full-rate opcodes (literals and inline constants do not): calibrated
         return cost.get("v_fma_f32(sgpr)", cost["v_fma_f32"])
     if base in cost:
         return cost[base]
@@ -192,7 +194,7 @@ def main():
             for lp in sorted(r["inner_loops"], key=lambda x: -x["valu"])[:4]:
                 print("   loop %s: %d VALU (%d SALU, %d VMEM, %d LDS)  issue %.0f cyc  mean %.2f  %s" % (
                     lp["span"], lp["valu"], lp["salu"], lp["vmem"], lp["lds"], lp["valu_issue_cycles"], lp["mean_cost"],
-                    " ".join("%s:%d" % (k.replace("v_", ""), v) for k, v in lp["top"][:10])))
+                    " ".join("%s:%d" % (k[2:] if k.startswith("v_") else k, v) for k, v in lp["top"][:10])))
             if r["unknown"]:
                 print("   unpriced (taken as half-rate):", r["unknown"])
     if args.json:
