@@ -20,8 +20,8 @@ Workloads (BASELINE.json configs):
 Frame streams shard one-stream-per-GPU (weak scaling): every rank runs the same
 workload on its own stream; the only cross-rank traffic is one scalar
 all-reduce (RCCL) of the pooled metrics after the timed region.  An RCCL failure
-at N > 1 is fatal on every rank (exit code 3) unless VQA_BENCH_DEVICE pins the
-ranks to one device, which is the 1-GPU rehearsal of the rank logic.
+at N > 1 is fatal on every rank (exit code 3).  VQA_BENCH_DEVICE pins every rank
+to one device: the 1-GPU rehearsal of the rank logic, which reduces over gloo.
 """
 import argparse
 import glob
@@ -168,7 +168,12 @@ def init_dist(backend, rank, world, device, rehearsal, stub):
     import torch
     import torch.distributed as td
     tmo = datetime.timedelta(seconds=300)
-    if backend == "gloo":
+    if backend == "gloo" or rehearsal:
+        # rehearsal = every rank pinned to ONE device (VQA_BENCH_DEVICE): RCCL refuses duplicate GPUs by design, so the
+        # scalar reductions of the rehearsal go over gloo from the start (no half-built NCCL group to tear down)
+        if rehearsal and backend != "gloo":
+            sys.stderr.write("[bench] rank %d: rehearsal (VQA_BENCH_DEVICE=%d): ranks share one device, scalar reductions over gloo\n"
+                             % (rank, device))
         td.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         return td, "gloo", "cpu", None
     try:  # device_id makes the RCCL communicator come up here, so a broken fabric shows now, on every rank
@@ -181,19 +186,9 @@ def init_dist(backend, rank, world, device, rehearsal, stub):
             raise RuntimeError("probe all-reduce returned %d, expected %d" % (got, world))
         return td, "nccl", "cuda", got
     except Exception as e:
-        if not rehearsal:
-            sys.stderr.write("[bench] rank %d: FATAL: RCCL bring-up failed on device %d: %s\n" % (rank, device, e))
-            sys.stderr.flush()
-            os._exit(3)  # every rank takes this path (the failure is collective); no JSON line is printed
-        sys.stderr.write("[bench] rank %d: rehearsal (VQA_BENCH_DEVICE=%d): RCCL refused (%s); scalar reductions over gloo\n"
-                         % (rank, device, str(e).splitlines()[0][:160]))
-        if td.is_initialized():
-            try:
-                td.destroy_process_group()
-            except Exception:
-                pass
-        td.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
-        return td, "gloo", "cpu", None
+        sys.stderr.write("[bench] rank %d: FATAL: RCCL bring-up failed on device %d: %s\n" % (rank, device, e))
+        sys.stderr.flush()
+        os._exit(3)  # every rank takes this path (the failure is collective); no JSON line is printed
 
 
 class StubEngine:

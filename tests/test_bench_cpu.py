@@ -82,8 +82,9 @@ def test_rccl_failure_is_fatal_unless_rehearsal(monkeypatch):
     # no GPU here: the nccl process group cannot come up
     r = _run([sys.executable, "-c", code % (REPO, str(_free_port()), "False")])
     assert r.returncode == 3 and "FATAL" in r.stderr and "FELLBACK" not in r.stdout
+    # the rehearsal (ranks pinned to one device) never touches RCCL: gloo from the start, and it says so
     r = _run([sys.executable, "-c", code % (REPO, str(_free_port()), "True")])
-    assert r.returncode == 0 and "FELLBACK gloo cpu None" in r.stdout, r.stderr[-600:]
+    assert r.returncode == 0 and "FELLBACK gloo cpu None" in r.stdout and "rehearsal" in r.stderr, r.stderr[-600:]
 
 
 def test_cpu_worker_rule(monkeypatch):
