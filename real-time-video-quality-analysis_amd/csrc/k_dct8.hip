@@ -272,12 +272,33 @@ __device__ __forceinline__ void march_load(dct_bytes &q, const uint8_t *plane, i
     }
 }
 
+// byte k of a dword as a float: ONE v_cvt_f32_ubyteN (asm so that the compiler cannot turn the first butterfly stage
+// into SDWA byte adds + shifts + v_cvt_f32_i32, which costs 232 instructions per block against 64 + 64 here)
+template <int K>
+__device__ __forceinline__ float ubf(uint32_t v)
+{
+    float f;
+    if (K == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(v));
+    else if (K == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(v));
+    else if (K == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(v));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(v));
+    return f;
+}
+
+// acc + |d| as ONE full-rate v_add_f32 with the abs source modifier (left to the compiler the sums are SLP-packed into
+// v_pk_add_f32, which has no abs modifier and needs a v_and_b32 per value on top of the half-rate packed add)
+__device__ __forceinline__ float abs_acc(float acc, float d)
+{
+    asm("v_add_f32_e64 %0, |%1|, %0" : "+v"(acc) : "v"(d));
+    return acc;
+}
+
 __device__ __forceinline__ void march_unpack(const dct_bytes &q, float *v)
 {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) { v[8 * r + k] = ub(q.lo[r], k); v[8 * r + 4 + k] = ub(q.hi[r], k); }
+        v[8 * r + 0] = ubf<0>(q.lo[r]); v[8 * r + 1] = ubf<1>(q.lo[r]); v[8 * r + 2] = ubf<2>(q.lo[r]); v[8 * r + 3] = ubf<3>(q.lo[r]);
+        v[8 * r + 4] = ubf<0>(q.hi[r]); v[8 * r + 5] = ubf<1>(q.hi[r]); v[8 * r + 6] = ubf<2>(q.hi[r]); v[8 * r + 7] = ubf<3>(q.hi[r]);
     }
 }
 
@@ -329,7 +350,7 @@ __global__ __launch_bounds__(256, RAGGED ? 2 : 3) void k_dct8_march(const uint8_
         }
         if (TEMPORAL && have_prev) {
 #pragma unroll
-            for (int i = 0; i < 64; i += 2) { t0 += fabsf(PRV[i] - CUR[i]); t1 += fabsf(PRV[i + 1] - CUR[i + 1]); }
+            for (int i = 0; i < 64; i += 2) { t0 = abs_acc(t0, PRV[i] - CUR[i]); t1 = abs_acc(t1, PRV[i + 1] - CUR[i + 1]); }
         }
         if (!LOAD_EARLY) { __builtin_amdgcn_sched_barrier(0); load(min(f + 2, n)); }
         const float e = wave_sum_dpp((e0 + e1) * keep);
@@ -427,31 +448,25 @@ static void launch_dct8_v(hipStream_t st, dim3 grid, const uint8_t *planes, int 
                            (int)first_has_prev, partials);
 }
 
-// frames per chunk of the marching kernel: every chunk pays one halo transform, and the grid should fill the
-// chip's wave slots in whole rounds.  cost(k chunks) ~ rounds(k) * (frames per chunk + 1)
+// frames per chunk of the marching kernel: every chunk pays one halo transform (1/chunk of extra work); more, smaller
+// chunks give the dispatcher finer grains at the tail of the grid.  Measured on 256 x 1080p and 64 x 2160p: 12..24
+// frames per chunk are within 2 % of each other and 3-5 % better than one grid-filling round of 43; so: 16, shrunk
+// until the grid has at least two waves per wave slot of the chip.
 static int dct_march_chunk(int n, int nw)
 {
     if (const char *e = getenv("VQA_DCT_FCH")) { const int v = atoi(e); if (v > 0) return v < n ? v : n; } // tuning knob
     static int slots = 0;
     if (!slots) {
-        int dev = 0, cus = 256, per_cu = 12;
+        int dev = 0, cus = 256, per_cu = 3;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dct8_march<true, true, false, false>, 256, 0) != hipSuccess || per_cu < 1)
-            per_cu = 12;
+            per_cu = 3;
         slots = cus * per_cu * 4; // waves
     }
-    long best_cost = -1;
-    int best = 1;
-    for (int k = 1; k <= n; k++) {
-        const int fch = (n + k - 1) / k, kk = (n + fch - 1) / fch;
-        const long total = (long)kk * nw;
-        const long rounds = (total + slots - 1) / slots;
-        const long cost = rounds * (fch + 1);
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && fch < best)) { best_cost = cost; best = fch; }
-        if (fch == 1) break;
-    }
-    return best;
+    int fch = n < 16 ? n : 16;
+    while (fch > 1 && (long)((n + fch - 1) / fch) * nw < 2L * slots) fch = (fch + 1) / 2;
+    return fch;
 }
 
 void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
