@@ -391,26 +391,32 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     const int y = ty * 64 + lane;
     const bool in_img = y < A.h;
     const int64_t idx = bp_index(f, in_img ? y : ty * 64, tx, A.ww, A.tiles_y);
+    // all of the tile's loads (own rows, left/right neighbours, the rows above and below) are issued BEFORE the
+    // "nothing to promote" test: one memory round trip per tile instead of two
     const u64 s0 = in_img ? A.strong[idx] : 0ull;
-    const u64 w = in_img ? (A.weak[idx] & ~s0) : 0ull;
-    if (!__any(w != 0)) return; // nothing here can be promoted
+    const u64 w0 = in_img ? A.weak[idx] : 0ull;
     // constant halo: the columns left / right of the tile and the rows above / below it.  Besides the
     // halo's edge bits (h*, e*) we keep its CANDIDATE bits (weak and not yet edge: c*, ec*): a neighbour is
     // only worth re-visiting if one of its candidates touches a pixel this tile promotes.
-    u64 hl = 0, hr = 0, cl = 0, cr = 0;
-    if (in_img && tx > 0) { const u64 sL = A.strong[idx - 64]; hl = sL >> 63; cl = (A.weak[idx - 64] & ~sL) >> 63; }
-    if (in_img && tx + 1 < A.ww) { const u64 sR = A.strong[idx + 64]; hr = sR & 1ull; cr = (A.weak[idx + 64] & ~sR) & 1ull; }
-    u64 es = 0, el = 0, er = 0, ecs = 0, ecl = 0, ecr = 0; // lane 0: row above the tile; lane 63: row below it
+    u64 sL = 0, wL = 0, sR = 0, wR = 0;
+    if (in_img && tx > 0) { sL = A.strong[idx - 64]; wL = A.weak[idx - 64]; }
+    if (in_img && tx + 1 < A.ww) { sR = A.strong[idx + 64]; wR = A.weak[idx + 64]; }
+    u64 es = 0, ew = 0, tl = 0, twl = 0, tr = 0, twr = 0; // lane 0: row above the tile; lane 63: row below it
     {
         const int yy = lane == 0 ? ty * 64 - 1 : (lane == 63 ? ty * 64 + 64 : -1);
         if (yy >= 0 && yy < A.h) {
             const int64_t j = bp_index(f, yy, tx, A.ww, A.tiles_y);
             es = A.strong[j];
-            ecs = A.weak[j] & ~es;
-            if (tx > 0) { const u64 t = A.strong[j - 64]; el = t >> 63; ecl = (A.weak[j - 64] & ~t) >> 63; }
-            if (tx + 1 < A.ww) { const u64 t = A.strong[j + 64]; er = t & 1ull; ecr = (A.weak[j + 64] & ~t) & 1ull; }
+            ew = A.weak[j];
+            if (tx > 0) { tl = A.strong[j - 64]; twl = A.weak[j - 64]; }
+            if (tx + 1 < A.ww) { tr = A.strong[j + 64]; twr = A.weak[j + 64]; }
         }
     }
+    const u64 w = w0 & ~s0;
+    if (!__any(w != 0)) return; // nothing here can be promoted
+    const u64 hl = sL >> 63, cl = (wL & ~sL) >> 63, hr = sR & 1ull, cr = (wR & ~sR) & 1ull;
+    const u64 ecs = ew & ~es;
+    const u64 el = tl >> 63, ecl = (twl & ~tl) >> 63, er = tr & 1ull, ecr = (twr & ~tr) & 1ull;
     const uint32_t hl32 = (uint32_t)hl, hr32 = (uint32_t)hr;
     uint32_t up_l = lane_up32(hl32), up_r = lane_up32(hr32);
     uint32_t dn_l = lane_dn32(hl32), dn_r = lane_dn32(hr32);
