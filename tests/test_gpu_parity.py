@@ -656,6 +656,47 @@ def test_pruned_block_sad_variant_is_bit_identical():
     assert r.returncode == 0 and "PRUNED-OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
 
 
+_VARIANT_CODE = (
+    "import sys, numpy as np; sys.path.insert(0, %r)\n"
+    "import rtvqa_amd\n"
+    "from rtvqa_amd import _native as N, synth\n"
+    "from rtvqa_amd.engine import bgr_planes\n"
+    "from oracle import c_oracle as co\n"
+    "from oracle import pipeline as pl\n"
+    "eng = rtvqa_amd.Engine(0)\n"
+    "for kind, h, w in (('natural', 270, 480), ('noise', 97, 131), ('natural', 64, 200)):\n"
+    "    fr = synth.s_natural(4, h, w, seed=9) if kind == 'natural' else synth.s_noise(4, h, w, seed=9)\n"
+    "    rec = eng.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8, canny=(40, 120))\n"
+    "    for i in range(3):\n"
+    "        g, gp = co.bgr2gray(fr[i + 1]), co.bgr2gray(fr[i])\n"
+    "        e, l1, _ = co.dct8x8(gp, g)\n"
+    "        assert abs(rec[i]['dct_energy'] - e) <= 1e-4 * e and abs(rec[i]['temporal_dct_l1'] - l1) <= 1e-4 * l1, ('dct', kind, i)\n"
+    "        assert int(rec[i]['edge_count']) == co.canny(g, 40, 120)[0] and not rec[i]['hyst_overflow'], ('canny', kind, i)\n"
+    "        nb, sad, hist = co.block_sad(gp, g, 7)\n"
+    "        assert int(rec[i]['sad_sum']) == sad and (rec[i]['mv_d2_hist'] == hist).all(), ('sad', kind, i)\n"
+    "    q = eng.quality(fr[:2], fr[1:3], bgr_planes(h, w), N.SSIM_GAUSS)\n"
+    "    sse, ssim = pl.frame_quality(fr[0], fr[1], bgr_planes(h, w), 'gauss')\n"
+    "    for p in range(3):\n"
+    "        assert int(q[0, p]['sse']) == sse[p] and abs(q[0, p]['ssim'] - ssim[p]) <= 1e-4 * abs(ssim[p]), ('ssim', kind, p)\n"
+    "print('VARIANT-OK')\n"
+)
+
+
+@pytest.mark.parametrize("knob", ["VQA_DCT_VARIANT=4", "VQA_DCT_VARIANT=3", "VQA_DCT_VARIANT=1", "VQA_DCT_LOAD_EARLY=1", "VQA_DCT_FCH=3",
+                                  "VQA_SSIM_VARIANT=1", "VQA_SSIM_VARIANT=4", "VQA_NMS_VARIANT=1", "VQA_HYST_SUB=1", "VQA_HYST_SUB=5",
+                                  "VQA_HYST_WIDE=1"])
+def test_ab_knob_variants_keep_parity(knob):
+    """Every A/B kernel variant kept in the library for re-measurement still matches the oracle
+    (the knobs are read once per process => one subprocess per setting)."""
+    import subprocess
+    import sys
+    k, v = knob.split("=")
+    env = dict(os.environ)
+    env[k] = v
+    r = subprocess.run([sys.executable, "-c", _VARIANT_CODE % REPO_ROOT], env=env, capture_output=True, text=True, timeout=600, cwd=REPO_ROOT)
+    assert r.returncode == 0 and "VARIANT-OK" in r.stdout, (knob, r.stdout[-300:], r.stderr[-1500:])
+
+
 def test_hysteresis_overflow_is_flagged():
     """The tail's round bound exists so the grid always drains; hitting it must SAY so (hyst_overflow = 1) instead of
     returning a silent under-count.  Forced here with VQA_HYST_MAX_ROUNDS=1 (read once per process => subprocess)."""
