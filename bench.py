@@ -81,6 +81,22 @@ def visible_cores():
         return os.cpu_count() or 1
 
 
+def cgroup_cpu_limit():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited/unknown.
+    Informational: the reference sizes its pool from os.cpu_count() and never looks at this."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except Exception:
+        return None
+
+
 def cpu_workers(cores):
     """num_workers exactly as the reference picks it (complexity_metrics.py:264-265): cores // 2.
     VQA_CPU_WORKERS overrides it explicitly (reported as workers_override)."""
@@ -109,7 +125,7 @@ def cpu_baseline(h, w, full, sample, motion="sad"):
             results.extend(ex.map(_cpu_item, items[i:i + 100]))
     dt = time.perf_counter() - t0
     return dict(value=round(sample / dt, 3), unit="frames/s", cores=cores, workers=workers, workers_override=override,
-                kind="port", seconds=round(dt, 2),
+                cgroup_cpu_limit=cgroup_cpu_limit(), kind="port", seconds=round(dt, 2),
                 sample="%d frame pairs of the same workload, oracle/ C port under ProcessPoolExecutor(max_workers="
                        "cores//2 = %d of the %d cores visible to the process), chunksize 1, batch_size 100"
                        % (sample, workers, cores))
