@@ -20,10 +20,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct Stamp { uint64_t t0, t1, r0, r1; uint32_t hwid, xcc; };
 
 enum Op { FMA, FMAC, ADDF, MULF, FMA_SGPR, PKFMA, PKFMA_SGPR, PKADDF, PKMULF, PKADDU16, PKSUBI16, PKMAXI16, CVTUB0, CVTUB3, QSAD, SADU8, DOT4, PERM,
-          ALIGNBIT, MADU24, MULLO, ADDU32, AND, LSHL, CNDMASK, MOV, MOVDPP, ADD3, LSHLADD, MAD64, BFE, MAX3F, SUBREVF, MINU32, CMPGT, NOPS, FMA_DEP, PKFMA_DEP, CND_SGPR, CND_VCC_FRESH, CMP_CND_PAIR, LSHR, OR, XOR, SUBU32, MAXF, MULU24, BFI, ANDOR, OR3, LSHLOR, CVTF32U32, CVTU32F32, RCP, FMA64, ADD64, MED3I, ADDCO, ASHR, PKMULLO16, PKMAD16, MAXI32, ABSDIFF, MUL_LIT, MUL_SGPR, FMAC_SGPR, FMAC_LIT, FMAMK, FMAAK, ADD_INL, FMA_NEG, FMA_INL, ADDU_SDWA, ADDF_SDWA, CVTI, ADD_SGPR, ADDU_SGPR, ADDU_LIT, MUL_ABS, N_OPS };
+          ALIGNBIT, MADU24, MULLO, ADDU32, AND, LSHL, CNDMASK, MOV, MOVDPP, ADD3, LSHLADD, MAD64, BFE, MAX3F, SUBREVF, MINU32, CMPGT, NOPS, FMA_DEP, PKFMA_DEP, CND_SGPR, CND_VCC_FRESH, CMP_CND_PAIR, LSHR, OR, XOR, SUBU32, MAXF, MULU24, BFI, ANDOR, OR3, LSHLOR, CVTF32U32, CVTU32F32, RCP, FMA64, ADD64, MED3I, ADDCO, ASHR, PKMULLO16, PKMAD16, MAXI32, ABSDIFF, MUL_LIT, MUL_SGPR, FMAC_SGPR, FMAC_LIT, FMAMK, FMAAK, ADD_INL, FMA_NEG, FMA_INL, ADDU_SDWA, ADDF_SDWA, CVTI, ADD_SGPR, ADDU_SGPR, ADDU_LIT, MUL_ABS, S_ADD, S_AND64, S_SAVEEXEC, S_MUL, VCMP_SGPR, N_OPS };
 static const char *op_names[N_OPS] = {"v_fma_f32", "v_fmac_f32", "v_add_f32", "v_mul_f32", "v_fma_f32(sgpr src)", "v_pk_fma_f32", "v_pk_fma_f32(sgpr src)", "v_pk_add_f32", "v_pk_mul_f32", "v_pk_add_u16", "v_pk_sub_i16", "v_pk_max_i16", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte3", "v_qsad_pk_u16_u8", "v_sad_u8", "v_dot4_u32_u8", "v_perm_b32",
-                                      "v_alignbit_b32", "v_mad_u32_u24", "v_mul_lo_u32", "v_add_u32", "v_and_b32", "v_lshlrev_b32", "v_cndmask_b32", "v_mov_b32", "v_mov_b32 dpp row_shr:1", "v_add3_u32", "v_lshl_add_u32", "v_mad_u64_u32", "v_bfe_u32", "v_max3_f32", "v_subrev_f32", "v_min_u32", "v_cmp_gt_u32", "s_nop 0", "v_fma_f32 (1 dependent chain)", "v_pk_fma_f32 (1 dependent chain)", "v_cndmask_b32 (sgpr-pair mask)", "v_cndmask_b32 (vcc written by s_mov each 16)", "v_cmp_gt_u32 + v_cndmask_b32 (pair = 2 instr)", "v_lshrrev_b32", "v_or_b32", "v_xor_b32", "v_sub_u32", "v_max_f32", "v_mul_u32_u24", "v_bfi_b32", "v_and_or_b32", "v_or3_b32", "v_lshl_or_b32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_rcp_f32", "v_fma_f64", "v_add_f64", "v_med3_i32", "v_add_co_u32", "v_ashrrev_i32", "v_pk_mul_lo_u16", "v_pk_mad_u16", "v_max_i32", "v_sad_u32", "v_mul_f32 (literal src)", "v_mul_f32 (sgpr src)", "v_fmac_f32 (sgpr src)", "v_fmac_f32 (literal src)", "v_fmamk_f32", "v_fmaak_f32", "v_add_f32 (inline const)", "v_fma_f32 (neg modifier)", "v_fma_f32 (inline const src)", "v_add_u32_sdwa (byte selects)", "v_add_f32_sdwa", "v_cvt_f32_i32", "v_add_f32 (sgpr src)", "v_add_u32 (sgpr src)", "v_add_u32 (literal src)", "v_add_f32 (abs modifier, e64)"};
-static const int op_lanes_mul[N_OPS] = {1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+                                      "v_alignbit_b32", "v_mad_u32_u24", "v_mul_lo_u32", "v_add_u32", "v_and_b32", "v_lshlrev_b32", "v_cndmask_b32", "v_mov_b32", "v_mov_b32 dpp row_shr:1", "v_add3_u32", "v_lshl_add_u32", "v_mad_u64_u32", "v_bfe_u32", "v_max3_f32", "v_subrev_f32", "v_min_u32", "v_cmp_gt_u32", "s_nop 0", "v_fma_f32 (1 dependent chain)", "v_pk_fma_f32 (1 dependent chain)", "v_cndmask_b32 (sgpr-pair mask)", "v_cndmask_b32 (vcc written by s_mov each 16)", "v_cmp_gt_u32 + v_cndmask_b32 (pair = 2 instr)", "v_lshrrev_b32", "v_or_b32", "v_xor_b32", "v_sub_u32", "v_max_f32", "v_mul_u32_u24", "v_bfi_b32", "v_and_or_b32", "v_or3_b32", "v_lshl_or_b32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_rcp_f32", "v_fma_f64", "v_add_f64", "v_med3_i32", "v_add_co_u32", "v_ashrrev_i32", "v_pk_mul_lo_u16", "v_pk_mad_u16", "v_max_i32", "v_sad_u32", "v_mul_f32 (literal src)", "v_mul_f32 (sgpr src)", "v_fmac_f32 (sgpr src)", "v_fmac_f32 (literal src)", "v_fmamk_f32", "v_fmaak_f32", "v_add_f32 (inline const)", "v_fma_f32 (neg modifier)", "v_fma_f32 (inline const src)", "v_add_u32_sdwa (byte selects)", "v_add_f32_sdwa", "v_cvt_f32_i32", "v_add_f32 (sgpr src)", "v_add_u32 (sgpr src)", "v_add_u32 (literal src)", "v_add_f32 (abs modifier, e64)", "s_add_u32", "s_and_b64", "s_and_saveexec_b64 + s_mov exec", "s_mul_i32", "v_cmp_gt_u32 (sgpr-pair dst, e64)"};
+static const int op_lanes_mul[N_OPS] = {1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 #define R16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
@@ -38,6 +38,8 @@ __global__ __launch_bounds__(1024) void k_calib(Stamp *st, const float *in, int 
     const uint32_t sbu = __builtin_amdgcn_readfirstlane(__float_as_uint(in[3])), scu = __builtin_amdgcn_readfirstlane(__float_as_uint(in[5]));
     const uint64_t sb2 = ((uint64_t)scu << 32) | sbu;
     const uint64_t q64 = 0x3ff0000000000001ull + threadIdx.x;
+    uint32_t su[4] = {sbu, scu, sbu + 1, scu + 1};
+    uint64_t sq[4] = {~0ull, ~0ull, ~0ull, ~0ull};
     const uint32_t ub = __float_as_uint(b) | 0x01020304u, uc = threadIdx.x * 2654435761u;
 #pragma unroll
     for (int i = 0; i < 16; i++) { a[i] = in[i & 7] + threadIdx.x + i; p[i] = f2{a[i], a[i] + 1.f}; u[i] = uc + i * 977u; q[i] = ((uint64_t)u[i] << 32) | ub; }
@@ -125,6 +127,11 @@ __global__ __launch_bounds__(1024) void k_calib(Stamp *st, const float *in, int 
 #define X_ADDUS(i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(u[i]) : "s"(sbu));
 #define X_ADDUL(i) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(u[i]));
 #define X_MULABS(i) asm volatile("v_add_f32_e64 %0, |%1|, %0" : "+v"(a[i]) : "v"(b));
+#define X_SADD(i) asm volatile("s_add_u32 %0, %0, 3" : "+s"(su[i & 3]) : : "scc");
+#define X_SAND(i) asm volatile("s_and_b64 %0, %0, %1" : "+s"(sq[i & 3]) : "s"(sb2) : "scc");
+#define X_SSAVE(i) asm volatile("s_and_saveexec_b64 %0, %1\n\ts_mov_b64 exec, %0" : "=&s"(sq[i & 3]) : "s"(sb2) : "scc", "exec");
+#define X_SMUL(i) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(su[i & 3]));
+#define X_VCMPS(i) asm volatile("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(sq[i & 3]) : "v"(u[i]), "v"(ub));
 #define X_FMADEP(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[0]) : "v"(b), "v"(c));
 #define X_PKFMADEP(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[0]) : "v"(b2), "v"(c2));
         if (OP == FMA) { R16(X_FMA) } else if (OP == FMAC) { R16(X_FMAC) } else if (OP == ADDF) { R16(X_ADDF) }
@@ -155,6 +162,8 @@ __global__ __launch_bounds__(1024) void k_calib(Stamp *st, const float *in, int 
         else if (OP == ADDU_SDWA) { R16(X_ADDUSDWA) } else if (OP == ADDF_SDWA) { R16(X_ADDFSDWA) } else if (OP == CVTI) { R16(X_CVTI) }
         else if (OP == ADD_SGPR) { R16(X_ADDS) } else if (OP == ADDU_SGPR) { R16(X_ADDUS) } else if (OP == ADDU_LIT) { R16(X_ADDUL) }
         else if (OP == MUL_ABS) { R16(X_MULABS) }
+        else if (OP == S_ADD) { R16(X_SADD) } else if (OP == S_AND64) { R16(X_SAND) } else if (OP == S_SAVEEXEC) { R16(X_SSAVE) }
+        else if (OP == S_MUL) { R16(X_SMUL) } else if (OP == VCMP_SGPR) { R16(X_VCMPS) }
     }
     uint64_t t1 = __builtin_amdgcn_s_memtime();
     uint64_t r1 = __builtin_amdgcn_s_memrealtime();
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_calib(Stamp *st, const float *in, int 
         Stamp &o = st[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)];
         o.t0 = t0; o.t1 = t1; o.r0 = r0; o.r1 = r1; o.hwid = hwid; o.xcc = xcc;
     }
-    if (s == 1.2345f && us == 77) st[0].t0 = 0; // keep results live
+    if (s == 1.2345f && us == 77 + su[0] + su[1] + su[2] + su[3] + (uint32_t)(sq[0] ^ sq[1] ^ sq[2] ^ sq[3])) st[0].t0 = 0; // keep results live
 }
 
 typedef void (*kfn)(Stamp *, const float *, int);
