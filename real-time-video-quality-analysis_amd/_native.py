@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvqa_hip.so")
+# VQA_LIB_PATH: load another build of the same ABI (A/B timing of two builds on one GPU box); default = the in-tree library
+LIB_PATH = os.environ.get("VQA_LIB_PATH") or os.path.join(_HERE, "csrc", "libvqa_hip.so")
 
 VQA_ABI_VERSION = 4
 

@@ -136,26 +136,35 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
     float ssim_acc = 0.f;
     uint32_t sse_acc = 0;
 
-    // pixel loads run PF rows ahead of the arithmetic (a shift register of PF byte pairs)
+    // Pixel loads run PF rows ahead of the arithmetic.  They are BUFFER loads: a scalar resource per plane, the
+    // lane's constant column offset as the vector offset and the row offset in a scalar register, so the vector ALUs
+    // spend nothing on addresses (the global_load form cost one v_lshl_add_u64 per load).  The queue of PF byte pairs
+    // is indexed statically: the row loop is unrolled over 22 rows (two turns of the 11-slot accumulator ring), so
+    // the slot (row mod PF) is a compile-time constant for PF = 1, 2 and no register is shifted.
+    static_assert(PF == 1 || PF == 2, "the 22-row unroll makes row mod PF static for PF = 1, 2");
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void *)rbase, (short)0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void *)dbase, (short)0, -1, 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t &rs, int rr) -> uint32_t {
+        return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, coff, (int)((int64_t)rr * row_stride), 0);
+    };
     uint32_t qr[PF], qd[PF];
 #pragma unroll
     for (int i = 0; i < PF; i++) {
         const int rr = min(i, nrows - 1);
-        qr[i] = uniform_ptr(rbase + (int64_t)rr * row_stride)[coff];
-        qd[i] = uniform_ptr(dbase + (int64_t)rr * row_stride)[coff];
+        qr[i] = ld(rres, rr);
+        qd[i] = ld(dres, rr);
     }
-    for (int r0 = 0; r0 < nrows; r0 += 11) {
+    for (int r0 = 0; r0 < nrows; r0 += 22) {
 #pragma unroll
-        for (int p = 0; p < 11; p++) {
-            const int r = r0 + p;
+        for (int p2 = 0; p2 < 22; p2++) {
+            const int p = p2 % 11;
+            const int r = r0 + p2;
             if (r < nrows) {
-                const uint32_t cr = qr[0], cd = qd[0];
-#pragma unroll
-                for (int i = 0; i + 1 < PF; i++) { qr[i] = qr[i + 1]; qd[i] = qd[i + 1]; }
+                const uint32_t cr = qr[p2 % PF], cd = qd[p2 % PF];
                 {
                     const int rr = min(r + PF, nrows - 1);
-                    qr[PF - 1] = uniform_ptr(rbase + (int64_t)rr * row_stride)[coff];
-                    qd[PF - 1] = uniform_ptr(dbase + (int64_t)rr * row_stride)[coff];
+                    qr[p2 % PF] = ld(rres, rr);
+                    qd[p2 % PF] = ld(dres, rr);
                 }
                 if (own_c && (last_sb || r < QS)) {
                     const int e = (int)cr - (int)cd;
