@@ -22,7 +22,8 @@ def process_dct_frame(frame, resize_width, resize_height, dct_mode="full"):
     gray_frame = co.bgr2gray(frame)
     gray_frame = co.resize_linear(gray_frame, resize_width, resize_height)
     if dct_mode == "full":
-        return np.float32(co.dct_energy_full(gray_frame))
+        dct_frame = co.dct2_full(np.float32(gray_frame))  # :363
+        return np.sum(dct_frame ** 2)                      # :364 — float32 pairwise sum, as NumPy does it
     return np.float32(co.dct8x8(None, gray_frame)[0])
 
 
@@ -61,7 +62,9 @@ def process_frame_complexity(frame_pair, sad_range=7, motion="sad"):
     curr_gray = co.bgr2gray(frame)
     prev_gray = co.bgr2gray(prev_frame)
     if motion == "farneback":
-        return np.float32(co.farneback(prev_gray, curr_gray))
+        flow = co.farneback(prev_gray, curr_gray, want_flow=True)[1]      # :340
+        fx, fy = flow[..., 0], flow[..., 1]
+        return np.mean(np.sqrt(fx * fx + fy * fy))                        # :342-343 (cartToPolar magnitude, f32)
     nb, _sad, hist = co.block_sad(prev_gray, curr_gray, sad_range)
     return np.float32(no.motion_mag_from_hist(hist, nb))
 
@@ -71,7 +74,9 @@ def process_temporal_dct_frame(prev_gray_frame, curr_gray_frame, resize_width, r
     prev_gray_frame = co.resize_linear(prev_gray_frame, resize_width, resize_height)
     curr_gray_frame = co.resize_linear(curr_gray_frame, resize_width, resize_height)
     if dct_mode == "full":
-        return np.float32(co.temporal_dct_full(prev_gray_frame, curr_gray_frame))
+        prev_frame_dct = co.dct2_full(np.float32(prev_gray_frame))         # :574
+        curr_frame_dct = co.dct2_full(np.float32(curr_gray_frame))         # :575
+        return np.sum(np.abs(prev_frame_dct - curr_frame_dct))             # :578
     return np.float32(co.dct8x8(prev_gray_frame, curr_gray_frame)[1])
 
 

@@ -401,19 +401,28 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
     return out
 
 
-def calculate_temporal_dct(video_path, resize_width, resize_height, frame_interval=10, smoothing_factor=0.8):
-    """complexity_metrics.py:506-541."""
-    s = complexity_series(video_path, resize_width, resize_height, frame_interval, mask=N.M_TEMPORAL_DCT)["temporal"]
+_DCT_MODES = {None: N.DCT_AUTO, "auto": N.DCT_AUTO, "full": N.DCT_FULL, "block8": N.DCT_BLOCK8}
+
+
+def calculate_temporal_dct(video_path, resize_width, resize_height, frame_interval=10, smoothing_factor=0.8,
+                           dct_mode=None):
+    """complexity_metrics.py:506-541.  dct_mode: None/"auto" (full-frame up to 128x128, 8x8 blocks above),
+    "full" (the reference's own full-frame cv2.dct metric at any size) or "block8" (north_star's metric)."""
+    s = complexity_series(video_path, resize_width, resize_height, frame_interval, mask=N.M_TEMPORAL_DCT,
+                          dct_mode=_DCT_MODES[dct_mode])["temporal"]
     sm = smooth_data(s, smoothing_factor)
     return np.mean(sm) if len(sm) > 0 else 0.0
 
 
 def calculate_average_scene_complexity(video_path, resize_width, resize_height, frame_interval=10,
-                                       smoothing_factor=0.8, num_workers=None, batch_size=100, fps=30.0):
+                                       smoothing_factor=0.8, num_workers=None, batch_size=100, fps=30.0,
+                                       dct_mode=None):
     """complexity_metrics.py:246-310.  Returns the 8-tuple in the reference's order (:301-310):
     (motion, dct, histogram, edge, orb, colour_histogram, temporal_dct, framerate_variation).
-    `video_path` may be a .npy path, an ndarray [N,H,W,3] or DeviceFrames."""
-    s = complexity_series(video_path, resize_width, resize_height, frame_interval, batch_size)
+    `video_path` may be a .npy path, an ndarray [N,H,W,3] or DeviceFrames; `fps` stands in for the container's
+    timestamps (:66) and `dct_mode` is as for calculate_temporal_dct."""
+    s = complexity_series(video_path, resize_width, resize_height, frame_interval, batch_size,
+                          dct_mode=_DCT_MODES[dct_mode])
 
     def pooled(x):
         with np.errstate(invalid="ignore"), _quiet_empty_mean():
