@@ -74,6 +74,47 @@ def _cpu_item(item):
     return out
 
 
+def stream_chunk(content, rank, h, w, a, n):
+    """Frames a .. a+n-1 of rank's synthetic stream (reference, distorted).  `a` is a multiple of CHUNK for noise
+    (its generator is seeded per chunk); the upload loop and the verification regenerate frames through this."""
+    from rtvqa_amd import synth
+    r = (synth.s_natural(n, h, w, seed=1234, stream_id=rank, t0=a) if content == "natural"
+         else synth.s_noise(n, h, w, seed=1234 + a, stream_id=rank))
+    return r, synth.distort(r, t0=a)
+
+
+CHUNK = 32
+
+
+def verify_frames(B):
+    """Batch positions checked against the oracle: both ends, the middle, and both sides of the first 16-frame
+    seam (the marching DCT's chunk boundary)."""
+    return sorted(set(j for j in (0, 1, 15, 16, 17, B // 2, B - 1) if 0 <= j < B))
+
+
+def _expect_item(item):
+    """Oracle's expected records for batch position j of the stream (stream index j+1; previous = stream index j)."""
+    from oracle import check
+    content, rank, h, w, B, j, full, motion, ssim_mode, yuv, dct_mode = item
+    if content == "natural":
+        r, d = stream_chunk(content, rank, h, w, j, 2)
+        ref, dist, prev = r[1], d[1], d[0]
+    else:  # noise: regenerate the chunk(s) holding stream frames j and j+1
+        got = {}
+        for i in (j, j + 1):
+            a = i // CHUNK * CHUNK
+            r, d = stream_chunk(content, rank, h, w, a, min(CHUNK, B + 1 - a))
+            got[i] = (r[i - a].copy(), d[i - a].copy())
+        ref, dist, prev = got[j + 1][0], got[j + 1][1], got[j][1]
+    planes = qpair = None
+    if yuv:
+        from rtvqa_amd.engine import yuv420p_planes
+        from rtvqa_amd.frames import bgr_to_yuv420p
+        planes = yuv420p_planes(h, w)
+        qpair = (bgr_to_yuv420p(ref[None])[0], bgr_to_yuv420p(dist[None])[0])
+    return j, check.expected(ref, dist, prev, full, (ssim_mode,), motion, planes, qpair, dct_mode)
+
+
 def visible_cores():
     try:
         return len(os.sched_getaffinity(0))  # the cores this process may run on
@@ -106,7 +147,7 @@ def cpu_workers(cores):
     return max(1, cores // 2), False
 
 
-def cpu_baseline(h, w, full, sample, motion="sad"):
+def cpu_baseline(h, w, full, sample, motion="sad", verify_items=()):
     from concurrent.futures import ProcessPoolExecutor
     from oracle import c_oracle as co
     from rtvqa_amd import synth
@@ -123,8 +164,9 @@ def cpu_baseline(h, w, full, sample, motion="sad"):
     with ProcessPoolExecutor(max_workers=workers) as ex:
         for i in range(0, len(items), 100):  # batch_size=100, barrier per batch (:144-147)
             results.extend(ex.map(_cpu_item, items[i:i + 100]))
-    dt = time.perf_counter() - t0
-    return dict(value=round(sample / dt, 3), unit="frames/s", cores=cores, workers=workers, workers_override=override,
+        dt = time.perf_counter() - t0
+        expect = dict(ex.map(_expect_item, verify_items))  # the checker for "verified": same pool, not timed
+    return expect, dict(value=round(sample / dt, 3), unit="frames/s", cores=cores, workers=workers, workers_override=override,
                 cgroup_cpu_limit=cgroup_cpu_limit(), kind="port", seconds=round(dt, 2),
                 sample="%d frame pairs of the same workload, oracle/ C port under ProcessPoolExecutor(max_workers="
                        "cores//2 = %d of the %d cores visible to the process), chunksize 1, batch_size 100"
@@ -283,6 +325,8 @@ def main():
                     help="block8 (default, north_star's 8x8 DCT) or full (the reference's full-frame cv2.dct, on fp32 MFMA)")
     ap.add_argument("--motion", default="sad", choices=["sad", "farneback"],
                     help="motion metric of the full suite: sad (north_star's block-SAD, default) or farneback (the reference's own)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false",
+                    help="skip the post-timing check of the last timed step's records against the oracle")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the rank logic)")
     ap.add_argument("--stub-engine", action="store_true",
@@ -302,10 +346,19 @@ def main():
     B = args.batch or wl["batch"]
     stub = args.stub_engine
 
-    # CPU baseline first: its worker processes are forked before this process touches the GPU
-    cpu_line = None
-    if world == 1 and rank == 0 and args.cpu_sample != 0 and not stub:
-        cpu_line = cpu_baseline(h, w, full, args.cpu_sample, args.motion)
+    # CPU baseline first: its worker processes are forked before this process touches the GPU.  The same leg
+    # computes the oracle's expected records for a few frames of this rank's stream (the checker of "verified").
+    cpu_line, expect = None, {}
+    yuv = args.pixfmt == "yuv420p"
+    if not stub and args.verify:
+        vj = verify_frames(B) if rank == 0 else sorted(set([0, B - 1]))
+        vitems = [(args.content, rank, h, w, B, j, full, args.motion, args.ssim_mode, yuv, args.dct_mode) for j in vj]
+        if world == 1 and args.cpu_sample != 0:
+            expect, cpu_line = cpu_baseline(h, w, full, args.cpu_sample, args.motion, vitems)
+        else:
+            expect = dict(_expect_item(it) for it in vitems)
+    elif world == 1 and rank == 0 and args.cpu_sample != 0 and not stub:
+        _, cpu_line = cpu_baseline(h, w, full, args.cpu_sample, args.motion)
 
     import torch
     rehearsal = "VQA_BENCH_DEVICE" in os.environ
@@ -347,7 +400,6 @@ def main():
         # ---- synthetic streams, generated in chunks and made resident in HBM before timing
         fbytes = h * w * 3
         ref_buf, dist_buf = DeviceBuffer(eng, fbytes * (B + 1)), DeviceBuffer(eng, fbytes * (B + 1))
-        yuv = args.pixfmt == "yuv420p"
         ybytes = frame_bytes_yuv420p(h, w)
         if yuv:
             yref_buf, ydist_buf = DeviceBuffer(eng, ybytes * (B + 1)), DeviceBuffer(eng, ybytes * (B + 1))
@@ -355,12 +407,9 @@ def main():
         Be = min(args.e2e_batch, B)
         if do_e2e:  # page-locked host copies of the first Be+1 frames for the end_to_end measurement
             ref_pin, dist_pin = eng.alloc_pinned((Be + 1, h, w, 3)), eng.alloc_pinned((Be + 1, h, w, 3))
-        chunk = 32
-        for a in range(0, B + 1, chunk):
-            n = min(chunk, B + 1 - a)
-            r = (synth.s_natural(n, h, w, seed=1234, stream_id=rank, t0=a) if args.content == "natural"
-                 else synth.s_noise(n, h, w, seed=1234 + a, stream_id=rank))
-            d = synth.distort(r, t0=a)
+        for a in range(0, B + 1, CHUNK):
+            n = min(CHUNK, B + 1 - a)
+            r, d = stream_chunk(args.content, rank, h, w, a, n)
             N.check(eng.lib.vqa_copy_h2d(eng.ctx, ref_buf.ptr + a * fbytes, r.ctypes.data, r.nbytes), "h2d", eng.ctx)
             N.check(eng.lib.vqa_copy_h2d(eng.ctx, dist_buf.ptr + a * fbytes, d.ctypes.data, d.nbytes), "h2d", eng.ctx)
             if yuv:
@@ -424,6 +473,32 @@ def main():
             prof.update(eng_q.profile_read(reset=True))  # NOTE: with 2 streams a launch's event time includes sharing the GPU
             eng_q.profile(False)
 
+    # ---- outside the timed region: the LAST TIMED step's records against the oracle's expectations
+    verified = None
+    if not stub and args.verify:
+        from oracle import check  # checker only: the expectations were computed before the GPU was touched
+        bad = {}
+        for j in sorted(expect):
+            m = check.compare(expect[j], c[j], q[j], args.ssim_mode)
+            if m:
+                bad[j] = m
+        verified = {"frames": sorted(expect), "ok": not bad, "step": "last timed",
+                    "fields": "sse exact, ssim 1e-4, dct_energy/temporal_dct_l1 1e-4 (+Parseval)"
+                              + (", edge count/strong/weak, sad sum + mv histogram, gray/B/G/R bins, orb count exact"
+                                 if full else ""),
+                    "checker": "oracle/check.py (expected records computed on the host before GPU init)"}
+        if bad:
+            sys.stderr.write("[bench] rank %d: FATAL: timed output differs from the oracle: %s\n" % (rank, json.dumps(bad)))
+            sys.stderr.flush()
+        if dist_on:
+            nbad = torch.tensor([float(len(bad))], dtype=torch.float64, device=red_dev)
+            td.all_reduce(nbad, op=td.ReduceOp.SUM)
+            if nbad.item() > 0:
+                os._exit(4)
+            verified["ranks"] = world
+        elif bad:
+            os._exit(4)  # no JSON line for a run whose output is wrong
+
     # ---- max over ranks, and the one scalar all-reduce the path has (pooled metrics)
     devices = [device]
     if dist_on:
@@ -466,7 +541,10 @@ def main():
                 # U+V: 2 * 2 * P/4), so the mean launch moves 1.5P per frame
                 "k_ssim_gauss": 2 * P * B * 3 if not yuv else int(1.5 * P * B),
                 "k_ssim_ffmpeg": 2 * P * B * 3 if not yuv else P * B,  # yuv420p: three planar launches, 3P in all
-                "k_dct8": 2 * P * B, "k_bgr2gray_hist": 4 * P * (B + 1),
+                # the marching kernel serves BOTH DCT metrics from one read of every gray plane (+ prev0; + one halo
+                # plane per internal chunk, not counted): P per frame.  SURVEY 8d's unfused figure (energy P +
+                # temporal 2P) is kept beside it as unfused_alg_bytes, never used for frac_hbm
+                "k_dct8": P * (B + 1), "k_bgr2gray_hist": 4 * P * (B + 1),
                 "k_canny_nms": P * B + P * B // 4,  # reads gray, writes two bit-planes (P/8 each)
                 "k_block_sad": 2 * P * B,
                 # Farneback, per level-0 pixel and pair, every kernel reading its inputs and writing its outputs once:
@@ -484,6 +562,15 @@ def main():
             tot = sum(ms for ms, _ in prof.values()) or 1.0
             for name, (ms, _) in prof.items():
                 kernels[name]["share_of_kernel_time"] = round(ms / tot, 4)
+            if "k_dct8" in kernels:
+                kernels["k_dct8"]["unfused_alg_bytes"] = 3 * P * B
+            # fp32 vector work of the Gaussian SSIM: separable 11+11 taps on 4 moment maps = 88 FMA per pixel and plane
+            # (DESIGN.md section 5); the vector-ALU peak is 157.3 TFLOP/s (MI355X_MICROARCH.md)
+            valu_fma = {"k_ssim_gauss": 88 * P * B * 3 if not yuv else int(88 * 1.5 * P * B / 2)}
+            for name, fma in valu_fma.items():
+                if name in kernels:
+                    tf = 2.0 * fma / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
+                    kernels[name].update({"fma": fma, "TFLOPps": round(tf, 1), "frac_fp32": round(tf / 157.3, 4)})
             mfma_flops = {"k_dct_full(gemm_nt x4)": 2 * 2.0 * (w * w * h + h * h * w) * B}  # energy + temporal, 2 products each
             for name, fl in mfma_flops.items():
                 if name in kernels:
@@ -498,13 +585,23 @@ def main():
                 default_mode = (args.ssim_mode == "gauss" and not yuv and args.content == "natural" and args.motion == "sad"
                                 and args.dct_mode == "block8" and args.streams == 1)
                 traffic, tsrc = pmc_traffic(args.workload, dom, B, default_mode)
-                roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "traffic_source": tsrc,
-                        "alg_bytes": alg_bytes[dom],
-                        "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"
-                                + ("; k_ssim_gauss is bound by vector-ALU issue, not HBM: 88 FMA per 2 input bytes, priced with the "
-                                   "measured issue costs of profiles/round2_valu_calib.json in DESIGN.md section 5"
-                                   if dom == "k_ssim_gauss" else "")}
+                if kernels[dom]["frac_hbm"] < 0.2 and "frac_fp32" in kernels[dom]:
+                    # a kernel this far below the HBM roof that does counted fp32 work is reported against the roof it
+                    # really has: the vector ALUs; the HBM figures stay beside it
+                    roof = {"bound": "valu_fp32", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": 157.3,
+                            "unit": "TFLOP/s", "frac": kernels[dom]["frac_fp32"], "fma": kernels[dom]["fma"],
+                            "frac_hbm": kernels[dom]["frac_hbm"], "achieved_hbm_GBps": kernels[dom]["GBps"],
+                            "peak_hbm_GBps": HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                            "alg_bytes": alg_bytes[dom],
+                            "note": "achieved = 2 x 88 FMA per pixel and plane / mean HIP-event duration; fp32 vector peak "
+                                    "157.3 TFLOP/s at 2.4 GHz; the kernel issues packed FMAs at the calibrated rate "
+                                    "(DESIGN.md 4b/5) and the chip holds ~1.7 GHz under it (profiles/round3_c3_clock.json); "
+                                    "frac_hbm = algorithmic bytes / time / 8 TB/s is kept for the HBM view"}
+                else:
+                    roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "traffic_source": tsrc,
+                            "alg_bytes": alg_bytes[dom],
+                            "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"}
             line.update({"data": "synthetic (synth.s_%s v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
                                  % (args.content, synth.GENERATOR_VERSION),
                          "config": config, "roofline": roof, "kernels": kernels})
@@ -513,6 +610,8 @@ def main():
                                                 bgr_planes(h, w), smode, args.e2e_steps)
             if cpu_line is not None:
                 line["cpu_baseline"] = cpu_line
+            if verified is not None:
+                line["verified"] = verified
             print(json.dumps(line), flush=True)
     if dist_on:
         td.barrier()
