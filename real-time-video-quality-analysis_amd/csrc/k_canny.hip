@@ -302,9 +302,262 @@ __global__ __launch_bounds__(64) void k_canny_nms2(const uint8_t *__restrict__ g
 }
 
 // ---------------------------------------------------------------------------
+// Stage 1, lane-per-column form (k_canny_nms3, the default): a wave still covers 256 columns x a 64-row strip
+// (= 4 hysteresis tiles), but lane L owns the FOUR COLUMNS x0 + 64 k + L (k = 0..3), so the 64 lanes of group k
+// are the 64 columns of tile k and a vector compare of group k IS that tile row's bit-plane word (one
+// v_cmp writing an SGPR pair): every NMS decision is taken on 64-pixel masks by the scalar unit, there is no
+// per-pixel branch, no nibble assembly and no unpacking.
+//   * gray: 3 buffer_load_ubyte per pixel (x-1, x, x+1; clamped column offsets are loop-invariant VGPRs, the row
+//     offset is the instruction's scalar offset), so addressing costs no vector instruction;
+//   * gradient, 8 vector instructions per pixel: h1 = p[x+1] - p[x-1], h2 = p[x-1] + 2 p[x] + p[x+1]; rows are
+//     combined through running sums (gx + 1024 = s[R-1] + s[R], s[R] = h1[R-1] + h1[R] + 512) and the L1
+//     magnitude is two v_sad_u32: ax = |gx + 1024 - 1024|, m = |h2[R] - h2[R-2]| + ax (gy is never formed);
+//   * horizontal neighbours: the five column groups (4 tiles + a halo group whose lane 63 / lane 0 are the
+//     columns left / right of the wave's span) form a ring; wave_ror:1 / wave_rol:1 DPP moves plus one select
+//     for the seam lane give every row's m[x-1] and m[x+1] once, when the row is new;
+//   * sector test on integers (TG22 fixed point, OpenCV's own): r = (ay << 15) - 13573 ax, horizontal iff r < 0,
+//     vertical iff r - (ax << 16) > 0, else diagonal with the sign test (gx ^ gy) < 0 = two compares;
+//   * all compares between two consecutive rows are made once, when the lower row is new, and serve both rows
+//     (as "below" of the upper one, as "above" of the lower one): only TWO rows of magnitudes live in registers,
+//     the upper row's partial decisions wait in scalar registers as masks;
+//   * lane r captures row r's words (v_writelane), so after the strip every lane holds its row of the 4 tiles -
+//     the layout the hysteresis uses - and the bit-planes leave as 512-byte contiguous tile stores.
+// ---------------------------------------------------------------------------
+// |a - b| + c: the compiler selects v_sad_u32 for this shape.  NOT inline asm: the hazard recognizer does not see
+// an asm statement as a vector-ALU reader, so a v_sad_u32 written in asm right behind the v_dot4_u32_u8 that
+// produces its operand misses the wait states gfx950 needs between a DOT result and its first VALU use and reads a
+// stale register (measured: wrong magnitudes whose pattern changed with unrelated code edits).
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return (max(a, b) - min(a, b)) + c; }
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134, 0xf, 0xf, false); }
+
+// lane `lane` of `old` <- the wave-uniform `val`.  The lane select goes through M0: a VOP3 on gfx9 reads at most one
+// SGPR besides it.  (M0 is otherwise unused here: these kernels have no LDS / GDS traffic.)
+__device__ __forceinline__ void set_m0(int lane) { asm volatile("s_mov_b32 m0, %0" : : "s"(lane) : "m0"); }
+__device__ __forceinline__ uint32_t writelane_m0(uint32_t old, uint32_t val)
+{
+    asm volatile("v_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val));
+    return old;
+}
+
+typedef unsigned long long u64;
+
+struct nms3_state {
+    // gradient pipeline, 5 column groups (0..3 = tiles, 4 = halo): previous row's h1, previous running sum,
+    // h2 of the two previous rows (slot = row parity)
+    uint32_t h1p[5], sp[5], h2[2][5];
+    // magnitudes of the previous mag row (slot PH^1) and the new one (slot PH), with their left / right shifted copies
+    uint32_t m[2][4], mL[2][4], mR[2][4];
+    // decisions of the previous mag row that wait for the row below it (wave-uniform masks)
+    u64 HH[4], VV[4], DO[4], DS[4], ST[4];
+    // captured words: lane r <-> row r of the strip
+    uint32_t cs[4][2], cw[4][2];
+    // gray bytes of the NEXT step's row, loaded one step ahead (the loop is otherwise a chain of dependent loads:
+    // with 4 waves per SIMD nothing else hides a row's memory latency)
+    uint32_t pn[5];
+};
+
+// one UNALIGNED dword per column group: the bytes at columns x-1 .. x+2 of the lane's pixel.  global_load_dword with
+// a scalar row base and a 32-bit lane offset (buffer loads ignore the low address bits of a dword access)
+typedef uint32_t u32_any __attribute__((aligned(1)));
+typedef const __attribute__((address_space(1))) u32_any *gptr_u32_any;
+__device__ __forceinline__ void nms3_load(uint32_t (&p)[5], const uint8_t *rs, const int (&off)[5], int R, int h, int pitch)
+{
+    const gptr_u8 row = uniform_ptr(rs + (int64_t)min(max(R, 0), h - 1) * pitch); // vertical border: replicate
+#pragma unroll
+    for (int g = 0; g < 5; g++) p[g] = *(gptr_u32_any)(row + (uint32_t)off[g]);
+}
+
+template <int PH, bool EDGE>
+__device__ __forceinline__ void nms3_step(nms3_state &S, int j, const uint8_t *rs, int pitch, int h, int y0,
+                                          const int (&off)[5], const uint32_t (&sel)[5], const uint32_t (&cmask)[5],
+                                          const u64 (&colmask)[4], int low, int high, bool lane0, bool lane63)
+{
+    const int R = y0 - 2 + j;            // gray row loaded by this step
+    const int yy = R - 1;                // magnitude row completed by this step
+    // ---- this row's bytes were requested by the previous step; request the next row's now
+    // (the fence keeps the scheduler from sinking the new loads below the arithmetic, which would turn the
+    // prefetch back into a load-use chain)
+    uint32_t p[5], nxt[5];
+    nms3_load(nxt, rs, off, R + 1, h, pitch);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 5; g++) { p[g] = S.pn[g]; S.pn[g] = nxt[g]; }
+    // ---- gradient + L1 magnitude of row yy
+    const bool row_in = yy >= 0 && yy < h;
+    uint32_t zero = 0;
+    asm("" : "+v"(zero));
+    uint32_t mnew[5], ax[4];
+    u64 sx[4], sy[4];
+#pragma unroll
+    for (int g = 0; g < 5; g++) {
+        // bytes 0..2 = p[x-1], p[x], p[x+1].  A wave that touches the image's left or right border loaded from a
+        // clamped offset and puts its bytes in place with one v_perm (replicated border); interior waves use
+        // the dword as it is (byte 3 = p[x+2] has weight 0 below)
+        const uint32_t v = EDGE ? __builtin_amdgcn_perm(p[g], p[g], sel[g]) : p[g];
+        const uint32_t h1 = ((v >> 16) & 0xffu) - (v & 0xffu);                 // v_sub_u32_sdwa
+        const uint32_t h2 = __builtin_amdgcn_udot4(v, 0x00010201u, 0u, false);   // p[x-1] + 2 p[x] + p[x+1]
+        const uint32_t s = S.h1p[g] + h1 + 512u;
+        const uint32_t gxb = S.sp[g] + s;                 // gx + 1024, always positive
+        const uint32_t a = sad_u32(gxb, 1024u, zero);     // |gx| (zero: an opaque 0, the + 0 would be folded and the pattern lost)
+        const uint32_t h2a = S.h2[PH][g];                 // row R-2 (same parity as R)
+        uint32_t m = sad_u32(h2, h2a, a) & cmask[g];      // |gx| + |gy|, 0 outside the image's columns
+        if (!row_in) m = 0u;                              // wave-uniform
+        mnew[g] = m;
+        __builtin_assume(a <= 1020u);
+        if (g < 4) {
+            ax[g] = a;
+            sx[g] = __ballot(gxb < 1024u);                // gx < 0
+            sy[g] = __ballot(h2 < h2a);                   // gy < 0
+        }
+        S.h1p[g] = h1; S.sp[g] = s; S.h2[PH][g] = h2;
+    }
+#ifndef NMS3_PROBE
+#define NMS3_PROBE 0   // measurement builds only (scripts/build_probes.sh): 1 no capture, 2 no decisions, 3 no neighbours either
+#endif
+    // ---- left / right neighbours of the new row through the ring H,0,1,2,3,H
+    if (NMS3_PROBE < 3) {
+        uint32_t rr[5], rl[5];
+#pragma unroll
+        for (int g = 0; g < 5; g++) { rr[g] = wave_ror1(mnew[g]); rl[g] = wave_rol1(mnew[g]); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            S.m[PH][k] = mnew[k];
+            S.mL[PH][k] = lane0 ? rr[k == 0 ? 4 : k - 1] : rr[k];
+            S.mR[PH][k] = lane63 ? rl[k == 3 ? 4 : k + 1] : rl[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { S.m[PH][k] = mnew[k] + mnew[4]; S.cs[k][0] += S.m[PH][k] + ax[k] + (uint32_t)sx[k] + (uint32_t)sy[k]; }
+    }
+    if (NMS3_PROBE >= 2) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) S.cs[k][1] += S.m[PH][k] + S.mL[PH][k] + S.mR[PH][k] + ax[k] + (uint32_t)sx[k] + (uint32_t)sy[k];
+        return;
+    }
+    // ---- per tile: finish the row above (it now has its lower neighbours), prepare the new row.  The scalar unit
+    // (one per CU, shared by the four SIMDs) is this kernel's scarcest resource: no per-class branches, M0 set once
+    const int yout = yy - 1 - y0; // strip row finished by this step
+    if (yout >= 0) set_m0(yout);  // wave-uniform; lane yout captures its row
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t m1 = S.m[PH][k], m1L = S.mL[PH][k], m1R = S.mR[PH][k];
+        const uint32_t m2 = S.m[PH ^ 1][k], m2L = S.mL[PH ^ 1][k], m2R = S.mR[PH ^ 1][k];
+        const u64 gt = __ballot(m1 > m2); // serves both rows: "m2 >= m1" of the row above, "m1 > m2" of the new row
+        // row above: vertical needs m2 >= m1, same-sign diagonal m2 > m1[x+1], opposite-sign diagonal m2 > m1[x-1]
+        const u64 keep = S.HH[k] | (S.VV[k] & ~gt) | (S.DS[k] & __ballot(m2 > m1R)) | (S.DO[k] & __ballot(m2 > m1L));
+        if (NMS3_PROBE == 1) { S.cs[k][0] += (uint32_t)(keep & S.ST[k]); S.cw[k][0] += (uint32_t)(keep >> 32); }
+        else if (yout >= 0) {
+            const u64 st = keep & S.ST[k], wk = keep & ~S.ST[k];
+            S.cs[k][0] = writelane_m0(S.cs[k][0], (uint32_t)st);
+            S.cs[k][1] = writelane_m0(S.cs[k][1], (uint32_t)(st >> 32));
+            S.cw[k][0] = writelane_m0(S.cw[k][0], (uint32_t)wk);
+            S.cw[k][1] = writelane_m0(S.cw[k][1], (uint32_t)(wk >> 32));
+        }
+        // new row as the centre: direction sectors, same-row and upward compares
+        u64 cand = __ballot((int)m1 > low);
+        if (EDGE) cand &= colmask[k]; // (m is 0 outside the image; this only matters for a negative threshold)
+        u64 HH = 0, VV = 0, DO = 0, DS = 0, ST = 0;
+        if (cand) {
+            // OpenCV: y = |gy| << 15, tg22x = |gx| * 13573, tg67x = tg22x + (|gx| << 16); horizontal iff y < tg22x,
+            // vertical iff y > tg67x.  With |gy| = m - |gx| both become compares of m << 15 (all values < 2^28)
+            const uint32_t u = m1 << 15;
+            const uint32_t t1 = __umul24(ax[k], 46341u);       // tg22x + (|gx| << 15)
+            const uint32_t t2 = t1 + (ax[k] << 16);            // tg67x + (|gx| << 15)
+            const u64 ch = __ballot(u < t1), cv = __ballot(u > t2);
+            const u64 opp = sx[k] ^ sy[k];
+            const u64 nh = cand & ~ch, ds = nh & ~cv;
+            HH = cand & ch & __ballot(m1 > m1L) & __ballot(m1 >= m1R);
+            VV = nh & cv & gt;
+            DS = ds & ~opp & __ballot(m1 > m2L);
+            DO = ds & opp & __ballot(m1 > m2R);
+            ST = __ballot((int)m1 > high);
+        }
+        S.HH[k] = HH; S.VV[k] = VV; S.DO[k] = DO; S.DS[k] = DS; S.ST[k] = ST;
+    }
+}
+
+// grid = (ceil(w / 256), ceil(h / 64), n_frames), block = 64 (one wave)
+__global__ __launch_bounds__(64) void k_canny_nms3(const uint8_t *__restrict__ gray, int pitch, int64_t plane_stride,
+                                                   int h, int w, int low, int high,
+                                                   unsigned long long *__restrict__ strong,
+                                                   unsigned long long *__restrict__ weak, int ww,
+                                                   vqa_frame_metrics *__restrict__ res)
+{
+    const int f = blockIdx.z;
+    const int lane = lane_id();
+    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * 64;
+    const uint8_t *rs = gray + (int64_t)f * plane_stride;
+    const int tiles_y = (h + 63) >> 6;
+    // column of (group, lane); the halo group holds x0 - 1 in lane 63 and x0 + 256 in lane 0.  Every lane loads
+    // the dword at clamp(x - 1, 0, w - 4); sel[] maps the replicated-border columns x-1, x, x+1 into that dword
+    int off[5];
+    uint32_t sel[5], cmask[5];
+    u64 colmask[4];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int x = k < 4 ? x0 + 64 * k + lane : (lane == 63 ? x0 - 1 : x0 + 256);
+        const bool in = x >= 0 && x < w && (k < 4 || lane == 0 || lane == 63);
+        cmask[k] = in ? ~0u : 0u;
+        if (k < 4) colmask[k] = __ballot(in);
+        const int xc = min(max(x, -1), w); // columns beyond the border behave like the first one outside (magnitude 0 anyway)
+        off[k] = min(max(xc - 1, 0), w - 4);
+        uint32_t sl = 0x0c000000u;
+#pragma unroll
+        for (int t = 0; t < 3; t++) sl |= (uint32_t)(min(max(xc - 1 + t, 0), w - 1) - off[k]) << (8 * t);
+        sel[k] = sl;
+    }
+    const bool edge = x0 == 0 || x0 + 259 > w; // wave-uniform: some lane's dword window (x-1 .. x+2) leaves the image
+    nms3_state S;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { S.h1p[k] = 0; S.sp[k] = 0; S.h2[0][k] = S.h2[1][k] = 0; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        S.m[0][k] = S.m[1][k] = S.mL[0][k] = S.mL[1][k] = S.mR[0][k] = S.mR[1][k] = 0;
+        S.HH[k] = S.VV[k] = S.DO[k] = S.DS[k] = S.ST[k] = 0;
+        S.cs[k][0] = S.cs[k][1] = S.cw[k][0] = S.cw[k][1] = 0;
+    }
+    const bool lane0 = lane == 0, lane63 = lane == 63;
+    const int rows_out = min(64, h - y0);
+    const int steps = rows_out + 4;
+    nms3_load(S.pn, rs, off, y0 - 2, h, pitch);
+    if (edge) {
+        for (int j0 = 0; j0 < steps; j0 += 2) {
+            nms3_step<0, true>(S, j0, rs, pitch, h, y0, off, sel, cmask, colmask, low, high, lane0, lane63);
+            if (j0 + 1 < steps) nms3_step<1, true>(S, j0 + 1, rs, pitch, h, y0, off, sel, cmask, colmask, low, high, lane0, lane63);
+        }
+    } else {
+        for (int j0 = 0; j0 < steps; j0 += 2) {
+            nms3_step<0, false>(S, j0, rs, pitch, h, y0, off, sel, cmask, colmask, low, high, lane0, lane63);
+            if (j0 + 1 < steps) nms3_step<1, false>(S, j0 + 1, rs, pitch, h, y0, off, sel, cmask, colmask, low, high, lane0, lane63);
+        }
+    }
+    // ---- lane r holds row y0 + r of the four tiles: contiguous tile stores, strong / weak totals
+    unsigned n_strong = 0, n_weak = 0;
+    if (lane < rows_out) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int tx = blockIdx.x * 4 + k;
+            if (tx < ww) {
+                const int64_t o = bp_index(f, y0 + lane, tx, ww, tiles_y);
+                strong[o] = (u64)S.cs[k][0] | ((u64)S.cs[k][1] << 32);
+                weak[o] = (u64)S.cw[k][0] | ((u64)S.cw[k][1] << 32);
+                n_strong += __popc(S.cs[k][0]) + __popc(S.cs[k][1]);
+                n_weak += __popc(S.cw[k][0]) + __popc(S.cw[k][1]);
+            }
+        }
+    }
+    n_strong = wave_sum(n_strong);
+    n_weak = wave_sum(n_weak);
+    if (lane == 0) {
+        if (n_strong) atomicAdd(&res[f].edge_strong, n_strong);
+        if (n_weak) atomicAdd(&res[f].edge_weak, n_weak);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Hysteresis on bit-planes.  Tile = 64 columns x 64 rows = one wave; lane r <-> row r.
 // ---------------------------------------------------------------------------
-typedef unsigned long long u64;
 
 __device__ __forceinline__ u64 shfl_up64(u64 v) { return __shfl_up(v, 1, 64); }
 __device__ __forceinline__ u64 shfl_dn64(u64 v) { return __shfl_down(v, 1, 64); }
@@ -564,9 +817,14 @@ void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t pl
                       vqa_frame_metrics *res)
 {
     if (n <= 0) return;
-    static int variant = -1; // A/B knob (VQA_NMS_VARIANT): 0 = register-rolling kernel (default), 1 = LDS-tile kernel
-    if (variant < 0) { const char *e = getenv("VQA_NMS_VARIANT"); variant = e ? atoi(e) : 0; }
-    if (variant == 1) {
+    // A/B knob (VQA_NMS_VARIANT): 3 = lane-per-column kernel (default), 2 = 4-pixels-per-lane register-rolling kernel
+    // (round 2's default), 1 = LDS-tile kernel (round 1)
+    static int variant = -1;
+    if (variant < 0) { const char *e = getenv("VQA_NMS_VARIANT"); variant = e ? atoi(e) : 3; }
+    if (variant == 3 && w >= 4) { // (the dword window needs 4 columns; narrower frames take the byte-load kernel)
+        hipLaunchKernelGGL(k_canny_nms3, dim3((w + 255) / 256, (h + 63) / 64, n), dim3(64), 0, st, gray, pitch,
+                           plane_stride, h, w, low, high, strong, weak, (w + 63) / 64, res);
+    } else if (variant == 1) {
         const canny_geom g = canny_tiles(h, w);
         hipLaunchKernelGGL(k_canny_nms, dim3(g.tiles_x, g.tiles_y, n), dim3(256), 0, st, gray, pitch, plane_stride, h, w,
                            low, high, strong, weak, (w + 63) / 64, res);
