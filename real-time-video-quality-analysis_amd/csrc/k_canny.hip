@@ -328,8 +328,8 @@ __global__ __launch_bounds__(64) void k_canny_nms2(const uint8_t *__restrict__ g
 // produces its operand misses the wait states gfx950 needs between a DOT result and its first VALU use and reads a
 // stale register (measured: wrong magnitudes whose pattern changed with unrelated code edits).
 __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return (max(a, b) - min(a, b)) + c; }
-__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xf, 0xf, false); }
-__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x13C, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x134, 0xf, 0xf, false); }
 
 // lane `lane` of `old` <- the wave-uniform `val`.  The lane select goes through M0: a VOP3 on gfx9 reads at most one
 // SGPR besides it.  (M0 is otherwise unused here: these kernels have no LDS / GDS traffic.)
@@ -401,9 +401,7 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const uint8_t *r
         const uint32_t gxb = S.sp[g] + s;                 // gx + 1024, always positive
         const uint32_t a = sad_u32(gxb, 1024u, zero);     // |gx| (zero: an opaque 0, the + 0 would be folded and the pattern lost)
         const uint32_t h2a = S.h2[PH][g];                 // row R-2 (same parity as R)
-        uint32_t m = sad_u32(h2, h2a, a) & cmask[g];      // |gx| + |gy|, 0 outside the image's columns
-        if (!row_in) m = 0u;                              // wave-uniform
-        mnew[g] = m;
+        mnew[g] = sad_u32(h2, h2a, a) & cmask[g];         // |gx| + |gy|, 0 outside the image's columns
         __builtin_assume(a <= 1020u);
         if (g < 4) {
             ax[g] = a;
@@ -411,6 +409,12 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const uint8_t *r
             sy[g] = __ballot(h2 < h2a);                   // gy < 0
         }
         S.h1p[g] = h1; S.sp[g] = s; S.h2[PH][g] = h2;
+    }
+    if (!row_in) { // rows -1 and h: a real (wave-uniform) branch, the asm keeps it from becoming five selects per row.
+        // The s_nop supplies the two wait states a DPP read needs after a vector write: the hazard recognizer does
+        // not look inside an asm statement (see sad_u32)
+#pragma unroll
+        for (int g = 0; g < 5; g++) asm volatile("v_mov_b32 %0, 0\n\ts_nop 1" : "=v"(mnew[g]));
     }
 #ifndef NMS3_PROBE
 #define NMS3_PROBE 0   // measurement builds only (scripts/build_probes.sh): 1 no capture, 2 no decisions, 3 no neighbours either
@@ -632,6 +636,7 @@ struct hyst_args {
     unsigned *out_count;      // one append counter per frame (a single global counter serialises ~1e5 atomics)
     vqa_frame_metrics *res;
     int sub;                  // cheap vertical sub-steps per horizontal flood (see relax_tile)
+    int stats;                // accumulate the diagnostic hyst_steps (one more atomic per tile visit)
 };
 
 // Relax one tile to its local fixpoint.  tile id = (f * tiles_y + ty) * ww + tx.  Whole wave calls this.
@@ -677,11 +682,39 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     if (lane == 63) { dn_l = (uint32_t)el; dn_r = (uint32_t)er; }
     const row64 wr = to_row(w), F = to_row(s0 | w), esr = to_row(es);
     row64 sr = to_row(s0);
+    unsigned steps = 0;
+    if (A.sub == 0) {
+        // Default schedule.  One iteration = ONE 3x3 dilation step (rows above/below by whole-wave DPP shifts whose
+        // `old` operand supplies the halo row to lane 0 / lane 63, then a 3-wide horizontal dilation of the OR of the
+        // three rows) followed by a flood along the rows done by the integer adder: for seeds S inside a mask F of
+        // runs, F + S carries from every seed to the end of its run, so (F & ~(F + S)) | S is the run filled from the
+        // seed towards bit 63; the other direction is the same on bit-reversed words.  A horizontal chain of any
+        // length closes in one iteration for ~20 instructions (the shift/and/or ladder it replaces took ~90).
+        const u64 F64 = s0 | w, rF64 = __builtin_bitreverse64(F64);
+        const uint32_t hl_any = up_l | hl32 | dn_l, hr_any = (up_r | hr32 | dn_r) << 31; // halo columns, three rows
+        u64 cur = s0;
+        for (;;) {
+            steps++;
+            const uint32_t lo = (uint32_t)cur, hi = (uint32_t)(cur >> 32);
+            const uint32_t up_lo = (uint32_t)__builtin_amdgcn_update_dpp((int)esr.lo, (int)lo, 0x138, 0xf, 0xf, false);
+            const uint32_t up_hi = (uint32_t)__builtin_amdgcn_update_dpp((int)esr.hi, (int)hi, 0x138, 0xf, 0xf, false);
+            const uint32_t dn_lo = (uint32_t)__builtin_amdgcn_update_dpp((int)esr.lo, (int)lo, 0x130, 0xf, 0xf, false);
+            const uint32_t dn_hi = (uint32_t)__builtin_amdgcn_update_dpp((int)esr.hi, (int)hi, 0x130, 0xf, 0xf, false);
+            const row64 v = row64{up_lo | lo | dn_lo, up_hi | hi | dn_hi};
+            const row64 vl = shl<1>(v), vr = shr<1>(v);
+            const uint32_t d_lo = v.lo | vl.lo | vr.lo | hl_any, d_hi = v.hi | vl.hi | vr.hi | hr_any;
+            const u64 cand = w & ~cur & ((u64)d_lo | ((u64)d_hi << 32));
+            if (!__any(cand != 0)) break; // nothing anywhere in the tile => fixpoint
+            const u64 seed = cur | cand;
+            const u64 rs = __builtin_bitreverse64(seed);
+            cur = (F64 & ~(F64 + seed)) | __builtin_bitreverse64(rF64 & ~(rF64 + rs)) | seed;
+        }
+        sr = to_row(cur);
+    } else {
     // One iteration = A.sub cheap sub-steps (each: rows above/below by lane shift, 3-wide dilation, promote the weak
     // cells that touch an edge cell: a chain advances one row per sub-step, diagonals included) followed by ONE
     // Kogge-Stone flood along the rows.  Promotion is monotone, so any schedule reaches the same fixpoint; a chain
     // that runs down the tile costs ~45 instructions per row instead of a whole flood (~130) per row.
-    unsigned steps = 0;
     for (;;) {
         steps++;
         uint32_t any_c = 0;
@@ -698,11 +731,12 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
         if (!__any(any_c != 0u)) break; // none anywhere in the tile during a whole iteration => fixpoint
         sr = flood_row(sr, F);
     }
+    }
     const u64 s = to_u64(sr);
     const u64 promoted = s & ~s0;
-    if (promoted) A.strong[idx] = s;
-    unsigned cnt = (unsigned)__popcll(promoted);
-    cnt = wave_sum(cnt);
+    if (A.stats && lane == 0) atomicAdd(&A.res[f].hyst_steps, steps); // diagnostic, VQA_HYST_STATS=1 only
+    if (!__any(promoted != 0)) return; // nothing changed: nothing to store, nobody to wake
+    if (promoted) A.strong[idx] = s;   // (the edge pixels are counted once, from the final plane: k_canny_count)
     // Which neighbours must be re-visited: those holding a candidate pixel 8-adjacent to a promoted one.
     // (Candidate bits may be stale by one promotion: stale edge bits only ever make this test MORE
     // inclusive, never less, because edges only grow.)
@@ -719,8 +753,6 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     const bool ULf = __any(lane == 0 && (ecl & pb0) != 0), URf = __any(lane == 0 && (ecr & pb63) != 0);
     const bool DLf = __any(lane == 63 && (ecl & pb0) != 0), DRf = __any(lane == 63 && (ecr & pb63) != 0);
     if (lane == 0) {
-        if (cnt) atomicAdd(&A.res[f].edge_count, cnt);
-        atomicAdd(&A.res[f].hyst_steps, steps);
         const bool nbr[8] = {ULf, Uf, URf, L, R, DLf, Df, DRf};
         const int dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
 #pragma unroll
@@ -805,11 +837,24 @@ __global__ __launch_bounds__(1024) void k_canny_hyst_tail(hyst_args A, unsigned 
     if (!reached_fixpoint && threadIdx.x == 0 && cnts[in][f] != 0) A.res[f].hyst_overflow = 1u;
 }
 
-// edge_count so far holds the promotions; add the strong pixels.
-__global__ void k_canny_finish(int n, vqa_frame_metrics *__restrict__ res)
+// np.sum(edges > 0) (complexity_metrics.py:504): the set bits of the final edge plane.  One pass over P/8 bytes per
+// frame replaces a popcount + wave reduction + atomic in every tile visit of the fixpoint.
+// grid = (ceil(tiles per frame / 32), n), block = 256: a wave walks 8 tiles, lane r <-> row r.
+__global__ __launch_bounds__(256) void k_canny_count(const unsigned long long *__restrict__ strong, int h, int ww,
+                                                     int tiles_y, vqa_frame_metrics *__restrict__ res)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < n) res[f].edge_count += res[f].edge_strong;
+    const int f = blockIdx.y, lane = lane_id();
+    const int tpf = tiles_y * ww;
+    unsigned cnt = 0;
+#pragma unroll 4
+    for (int i = 0; i < 8; i++) {
+        const int t = (blockIdx.x * 4 + wave_id()) * 8 + i;
+        if (t >= tpf) break;
+        const int ty = t / ww;
+        if (ty * 64 + lane < h) cnt += (unsigned)__popcll(strong[((int64_t)f * tpf + t) * 64 + lane]);
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0 && cnt) atomicAdd(&res[f].edge_count, cnt);
 }
 
 void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int n, int h, int w,
@@ -843,9 +888,12 @@ static hyst_args make_hyst_args(unsigned long long *strong, const unsigned long 
     static int sub = 0;
     if (!sub) { // A/B knob VQA_HYST_SUB (1 = one vertical step per flood, the round-1 schedule)
         const char *e = getenv("VQA_HYST_SUB");
-        sub = (e && atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 2;
+        sub = (e && atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0; // 0 = dilation + carry flood (default); 1..8 = round 2's ladder
     }
     A.sub = sub;
+    static int stats = -1;
+    if (stats < 0) { const char *e = getenv("VQA_HYST_STATS"); stats = (e && atoi(e) > 0) ? 1 : 0; }
+    A.stats = stats;
     return A;
 }
 
@@ -891,10 +939,11 @@ void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const un
                        q1, first_in, max_rounds);
 }
 
-void launch_canny_finish(hipStream_t st, int n, vqa_frame_metrics *res)
+void launch_canny_finish(hipStream_t st, const unsigned long long *strong, int n, int h, int w, vqa_frame_metrics *res)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_canny_finish, dim3((n + 63) / 64), dim3(64), 0, st, n, res);
+    const int ww = (w + 63) / 64, tiles_y = (h + 63) / 64;
+    hipLaunchKernelGGL(k_canny_count, dim3((tiles_y * ww + 31) / 32, n), dim3(256), 0, st, strong, h, ww, tiles_y, res);
 }
 
 } // namespace vqa

@@ -744,7 +744,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             launch_canny_hyst_tail(st, strong, weak, n, ph, pw, lists[0], counts, queued[0], lists[1], counts + n,
                                    queued[1], round & 1, res);
         }
-        launch_canny_finish(st, n, res);
+        launch_canny_finish(st, strong, n, ph, pw, res);
         c->last_has_state = true;
     }
 

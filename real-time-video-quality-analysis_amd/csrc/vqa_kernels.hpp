@@ -50,7 +50,7 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
 void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *list0, unsigned *cnt0, unsigned *q0, unsigned *list1, unsigned *cnt1,
                             unsigned *q1, int first_in, vqa_frame_metrics *res);
-void launch_canny_finish(hipStream_t st, int n, vqa_frame_metrics *res);
+void launch_canny_finish(hipStream_t st, const unsigned long long *strong, int n, int h, int w, vqa_frame_metrics *res);
 
 // k_sad.hip
 void launch_block_sad(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,

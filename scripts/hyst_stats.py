@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, rtvqa_amd
 from rtvqa_amd import _native as N, synth
+os.environ["VQA_HYST_STATS"] = "1"
 eng = rtvqa_amd.Engine(0)
 h, w, B = 1080, 1920, 16
 for kind in ("natural", "noise"):
