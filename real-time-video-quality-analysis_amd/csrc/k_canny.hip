@@ -345,31 +345,30 @@ typedef unsigned long long u64;
 struct nms3_state {
     // gradient pipeline, 5 column groups (0..3 = tiles, 4 = halo): previous row's h1, previous running sum,
     // h2 of the two previous rows (slot = row parity)
-    uint32_t h1p[5], sp[5], h2[2][5];
+    uint32_t h1[2][5], s[2][5], h2[2][5]; // slot = row parity: nothing rotates through register copies
     // magnitudes of the previous mag row (slot PH^1) and the new one (slot PH), with their left / right shifted copies
     uint32_t m[2][4], mL[2][4], mR[2][4];
     // decisions of the previous mag row that wait for the row below it (wave-uniform masks)
-    u64 HH[4], VV[4], DO[4], DS[4], ST[4];
+    u64 HH[4], VV[4], DO[4], DS[4];
     // captured words: lane r <-> row r of the strip
     uint32_t cs[4][2], cw[4][2];
     // gray bytes of the NEXT step's row, loaded one step ahead (the loop is otherwise a chain of dependent loads:
     // with 4 waves per SIMD nothing else hides a row's memory latency)
-    uint32_t pn[5];
+    uint32_t pn[2][5];
 };
 
-// one UNALIGNED dword per column group: the bytes at columns x-1 .. x+2 of the lane's pixel.  global_load_dword with
-// a scalar row base and a 32-bit lane offset (buffer loads ignore the low address bits of a dword access)
-typedef uint32_t u32_any __attribute__((aligned(1)));
-typedef const __attribute__((address_space(1))) u32_any *gptr_u32_any;
-__device__ __forceinline__ void nms3_load(uint32_t (&p)[5], const uint8_t *rs, const int (&off)[5], int R, int h, int pitch)
+// one UNALIGNED dword per column group: the bytes at columns x-1 .. x+2 of the lane's pixel.  Buffer loads: the lane
+// offset is a loop-invariant VGPR and the row offset the instruction's scalar offset, so addressing costs no vector
+// instruction (byte-unaligned dword addresses are honoured: scripts/probes/unaligned_dword.hip)
+__device__ __forceinline__ void nms3_load(uint32_t (&p)[5], const __amdgpu_buffer_rsrc_t rs, const int (&off)[5], int R, int h, int pitch)
 {
-    const gptr_u8 row = uniform_ptr(rs + (int64_t)min(max(R, 0), h - 1) * pitch); // vertical border: replicate
+    const int soff = min(max(R, 0), h - 1) * pitch; // vertical border: replicate
 #pragma unroll
-    for (int g = 0; g < 5; g++) p[g] = *(gptr_u32_any)(row + (uint32_t)off[g]);
+    for (int g = 0; g < 5; g++) p[g] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, off[g], soff, 0);
 }
 
 template <int PH, bool EDGE>
-__device__ __forceinline__ void nms3_step(nms3_state &S, int j, const uint8_t *rs, int pitch, int h, int y0,
+__device__ __forceinline__ void nms3_step(nms3_state &S, int j, const __amdgpu_buffer_rsrc_t rs, int pitch, int h, int y0,
                                           const int (&off)[5], const uint32_t (&sel)[5], const uint32_t (&cmask)[5],
                                           const u64 (&colmask)[4], int low, int high, bool lane0, bool lane63)
 {
@@ -378,17 +377,15 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const uint8_t *r
     // ---- this row's bytes were requested by the previous step; request the next row's now
     // (the fence keeps the scheduler from sinking the new loads below the arithmetic, which would turn the
     // prefetch back into a load-use chain)
-    uint32_t p[5], nxt[5];
-    nms3_load(nxt, rs, off, R + 1, h, pitch);
+    nms3_load(S.pn[PH ^ 1], rs, off, R + 1, h, pitch);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 5; g++) { p[g] = S.pn[g]; S.pn[g] = nxt[g]; }
+    const uint32_t (&p)[5] = S.pn[PH];
     // ---- gradient + L1 magnitude of row yy
     const bool row_in = yy >= 0 && yy < h;
     uint32_t zero = 0;
     asm("" : "+v"(zero));
     uint32_t mnew[5], ax[4];
-    u64 sx[4], sy[4];
+    u64 opp[4];
 #pragma unroll
     for (int g = 0; g < 5; g++) {
         // bytes 0..2 = p[x-1], p[x], p[x+1].  A wave that touches the image's left or right border loaded from a
@@ -397,18 +394,17 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const uint8_t *r
         const uint32_t v = EDGE ? __builtin_amdgcn_perm(p[g], p[g], sel[g]) : p[g];
         const uint32_t h1 = ((v >> 16) & 0xffu) - (v & 0xffu);                 // v_sub_u32_sdwa
         const uint32_t h2 = __builtin_amdgcn_udot4(v, 0x00010201u, 0u, false);   // p[x-1] + 2 p[x] + p[x+1]
-        const uint32_t s = S.h1p[g] + h1 + 512u;
-        const uint32_t gxb = S.sp[g] + s;                 // gx + 1024, always positive
+        const uint32_t s = S.h1[PH ^ 1][g] + h1 + 512u;
+        const uint32_t gxb = S.s[PH ^ 1][g] + s;          // gx + 1024, always positive
         const uint32_t a = sad_u32(gxb, 1024u, zero);     // |gx| (zero: an opaque 0, the + 0 would be folded and the pattern lost)
         const uint32_t h2a = S.h2[PH][g];                 // row R-2 (same parity as R)
         mnew[g] = sad_u32(h2, h2a, a) & cmask[g];         // |gx| + |gy|, 0 outside the image's columns
         __builtin_assume(a <= 1020u);
         if (g < 4) {
             ax[g] = a;
-            sx[g] = __ballot(gxb < 1024u);                // gx < 0
-            sy[g] = __ballot(h2 < h2a);                   // gy < 0
+            opp[g] = __ballot(gxb < 1024u) ^ __ballot(h2 < h2a); // (gx ^ gy) < 0: gx < 0 differs from gy < 0
         }
-        S.h1p[g] = h1; S.sp[g] = s; S.h2[PH][g] = h2;
+        S.h1[PH][g] = h1; S.s[PH][g] = s; S.h2[PH][g] = h2;
     }
     if (!row_in) { // rows -1 and h: a real (wave-uniform) branch, the asm keeps it from becoming five selects per row.
         // The s_nop supplies the two wait states a DPP read needs after a vector write: the hazard recognizer does
@@ -421,28 +417,29 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const uint8_t *r
 #endif
     // ---- left / right neighbours of the new row through the ring H,0,1,2,3,H
     if (NMS3_PROBE < 3) {
-        uint32_t rr[5], rl[5];
-#pragma unroll
-        for (int g = 0; g < 5; g++) { rr[g] = wave_ror1(mnew[g]); rl[g] = wave_rol1(mnew[g]); }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            S.m[PH][k] = mnew[k];
-            S.mL[PH][k] = lane0 ? rr[k == 0 ? 4 : k - 1] : rr[k];
-            S.mR[PH][k] = lane63 ? rl[k == 3 ? 4 : k + 1] : rl[k];
-        }
+        // (named scalars, not arrays: the optimiser turns "lane0 ? a[i] : a[j]" into a select of the INDEX followed by
+        // a four-deep select chain over the array)
+        const uint32_t r0 = wave_ror1(mnew[0]), r1 = wave_ror1(mnew[1]), r2 = wave_ror1(mnew[2]), r3 = wave_ror1(mnew[3]);
+        const uint32_t rH = wave_ror1(mnew[4]);
+        const uint32_t l0 = wave_rol1(mnew[0]), l1 = wave_rol1(mnew[1]), l2 = wave_rol1(mnew[2]), l3 = wave_rol1(mnew[3]);
+        const uint32_t lH = wave_rol1(mnew[4]);
+        S.m[PH][0] = mnew[0]; S.m[PH][1] = mnew[1]; S.m[PH][2] = mnew[2]; S.m[PH][3] = mnew[3];
+        S.mL[PH][0] = lane0 ? rH : r0; S.mL[PH][1] = lane0 ? r0 : r1; S.mL[PH][2] = lane0 ? r1 : r2; S.mL[PH][3] = lane0 ? r2 : r3;
+        S.mR[PH][0] = lane63 ? l1 : l0; S.mR[PH][1] = lane63 ? l2 : l1; S.mR[PH][2] = lane63 ? l3 : l2; S.mR[PH][3] = lane63 ? lH : l3;
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) { S.m[PH][k] = mnew[k] + mnew[4]; S.cs[k][0] += S.m[PH][k] + ax[k] + (uint32_t)sx[k] + (uint32_t)sy[k]; }
+        for (int k = 0; k < 4; k++) { S.m[PH][k] = mnew[k] + mnew[4]; S.cs[k][0] += S.m[PH][k] + ax[k] + (uint32_t)opp[k]; }
     }
     if (NMS3_PROBE >= 2) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) S.cs[k][1] += S.m[PH][k] + S.mL[PH][k] + S.mR[PH][k] + ax[k] + (uint32_t)sx[k] + (uint32_t)sy[k];
+        for (int k = 0; k < 4; k++) S.cs[k][1] += S.m[PH][k] + S.mL[PH][k] + S.mR[PH][k] + ax[k] + (uint32_t)opp[k];
         return;
     }
     // ---- per tile: finish the row above (it now has its lower neighbours), prepare the new row.  The scalar unit
     // (one per CU, shared by the four SIMDs) is this kernel's scarcest resource: no per-class branches, M0 set once
     const int yout = yy - 1 - y0; // strip row finished by this step
     if (yout >= 0) set_m0(yout);  // wave-uniform; lane yout captures its row
+    u64 ST_new[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t m1 = S.m[PH][k], m1L = S.mL[PH][k], m1R = S.mR[PH][k];
@@ -450,34 +447,40 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const uint8_t *r
         const u64 gt = __ballot(m1 > m2); // serves both rows: "m2 >= m1" of the row above, "m1 > m2" of the new row
         // row above: vertical needs m2 >= m1, same-sign diagonal m2 > m1[x+1], opposite-sign diagonal m2 > m1[x-1]
         const u64 keep = S.HH[k] | (S.VV[k] & ~gt) | (S.DS[k] & __ballot(m2 > m1R)) | (S.DO[k] & __ballot(m2 > m1L));
-        if (NMS3_PROBE == 1) { S.cs[k][0] += (uint32_t)(keep & S.ST[k]); S.cw[k][0] += (uint32_t)(keep >> 32); }
-        else if (yout >= 0) {
-            const u64 st = keep & S.ST[k], wk = keep & ~S.ST[k];
-            S.cs[k][0] = writelane_m0(S.cs[k][0], (uint32_t)st);
-            S.cs[k][1] = writelane_m0(S.cs[k][1], (uint32_t)(st >> 32));
-            S.cw[k][0] = writelane_m0(S.cw[k][0], (uint32_t)wk);
-            S.cw[k][1] = writelane_m0(S.cw[k][1], (uint32_t)(wk >> 32));
+        if (NMS3_PROBE == 1) { S.cs[k][0] += (uint32_t)keep; S.cw[k][0] += (uint32_t)(keep >> 32); }
+        else if (yout >= 0) { // lane yout captures the row's kept pixels (its above-high word was captured a step ago)
+            S.cs[k][0] = writelane_m0(S.cs[k][0], (uint32_t)keep);
+            S.cs[k][1] = writelane_m0(S.cs[k][1], (uint32_t)(keep >> 32));
         }
         // new row as the centre: direction sectors, same-row and upward compares
         u64 cand = __ballot((int)m1 > low);
         if (EDGE) cand &= colmask[k]; // (m is 0 outside the image; this only matters for a negative threshold)
         u64 HH = 0, VV = 0, DO = 0, DS = 0, ST = 0;
-        if (cand) {
+        if (cand) { // (also keeps the masks of one tile from being live across the next tile's compares: without it the
+                    // scheduler hoists every compare and the kernel spills scalar registers)
             // OpenCV: y = |gy| << 15, tg22x = |gx| * 13573, tg67x = tg22x + (|gx| << 16); horizontal iff y < tg22x,
             // vertical iff y > tg67x.  With |gy| = m - |gx| both become compares of m << 15 (all values < 2^28)
             const uint32_t u = m1 << 15;
             const uint32_t t1 = __umul24(ax[k], 46341u);       // tg22x + (|gx| << 15)
             const uint32_t t2 = t1 + (ax[k] << 16);            // tg67x + (|gx| << 15)
             const u64 ch = __ballot(u < t1), cv = __ballot(u > t2);
-            const u64 opp = sx[k] ^ sy[k];
             const u64 nh = cand & ~ch, ds = nh & ~cv;
             HH = cand & ch & __ballot(m1 > m1L) & __ballot(m1 >= m1R);
             VV = nh & cv & gt;
-            DS = ds & ~opp & __ballot(m1 > m2L);
-            DO = ds & opp & __ballot(m1 > m2R);
+            DS = ds & ~opp[k] & __ballot(m1 > m2L);
+            DO = ds & opp[k] & __ballot(m1 > m2R);
             ST = __ballot((int)m1 > high);
         }
-        S.HH[k] = HH; S.VV[k] = VV; S.DO[k] = DO; S.DS[k] = DS; S.ST[k] = ST;
+        S.HH[k] = HH; S.VV[k] = VV; S.DO[k] = DO; S.DS[k] = DS; ST_new[k] = ST;
+    }
+    // the new row's above-high words go to lane yout + 1 now: one more M0 write per step, 8 scalar registers fewer to carry
+    if (NMS3_PROBE != 1 && yout + 1 >= 0 && yout + 1 < 64) {
+        set_m0(yout + 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            S.cw[k][0] = writelane_m0(S.cw[k][0], (uint32_t)ST_new[k]);
+            S.cw[k][1] = writelane_m0(S.cw[k][1], (uint32_t)(ST_new[k] >> 32));
+        }
     }
 }
 
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(64) void k_canny_nms3(const uint8_t *__restrict__ g
     const int f = blockIdx.z;
     const int lane = lane_id();
     const int x0 = blockIdx.x * 256, y0 = blockIdx.y * 64;
-    const uint8_t *rs = gray + (int64_t)f * plane_stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(gray + (int64_t)f * plane_stride), (short)0, -1, 0x00020000);
     const int tiles_y = (h + 63) >> 6;
     // column of (group, lane); the halo group holds x0 - 1 in lane 63 and x0 + 256 in lane 0.  Every lane loads
     // the dword at clamp(x - 1, 0, w - 4); sel[] maps the replicated-border columns x-1, x, x+1 into that dword
@@ -514,17 +517,17 @@ __global__ __launch_bounds__(64) void k_canny_nms3(const uint8_t *__restrict__ g
     const bool edge = x0 == 0 || x0 + 259 > w; // wave-uniform: some lane's dword window (x-1 .. x+2) leaves the image
     nms3_state S;
 #pragma unroll
-    for (int k = 0; k < 5; k++) { S.h1p[k] = 0; S.sp[k] = 0; S.h2[0][k] = S.h2[1][k] = 0; }
+    for (int k = 0; k < 5; k++) { S.h1[0][k] = S.h1[1][k] = S.s[0][k] = S.s[1][k] = S.h2[0][k] = S.h2[1][k] = 0; }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         S.m[0][k] = S.m[1][k] = S.mL[0][k] = S.mL[1][k] = S.mR[0][k] = S.mR[1][k] = 0;
-        S.HH[k] = S.VV[k] = S.DO[k] = S.DS[k] = S.ST[k] = 0;
+        S.HH[k] = S.VV[k] = S.DO[k] = S.DS[k] = 0;
         S.cs[k][0] = S.cs[k][1] = S.cw[k][0] = S.cw[k][1] = 0;
     }
     const bool lane0 = lane == 0, lane63 = lane == 63;
     const int rows_out = min(64, h - y0);
     const int steps = rows_out + 4;
-    nms3_load(S.pn, rs, off, y0 - 2, h, pitch);
+    nms3_load(S.pn[0], rs, off, y0 - 2, h, pitch);
     if (edge) {
         for (int j0 = 0; j0 < steps; j0 += 2) {
             nms3_step<0, true>(S, j0, rs, pitch, h, y0, off, sel, cmask, colmask, low, high, lane0, lane63);
@@ -544,10 +547,12 @@ __global__ __launch_bounds__(64) void k_canny_nms3(const uint8_t *__restrict__ g
             const int tx = blockIdx.x * 4 + k;
             if (tx < ww) {
                 const int64_t o = bp_index(f, y0 + lane, tx, ww, tiles_y);
-                strong[o] = (u64)S.cs[k][0] | ((u64)S.cs[k][1] << 32);
-                weak[o] = (u64)S.cw[k][0] | ((u64)S.cw[k][1] << 32);
-                n_strong += __popc(S.cs[k][0]) + __popc(S.cs[k][1]);
-                n_weak += __popc(S.cw[k][0]) + __popc(S.cw[k][1]);
+                const uint32_t s_lo = S.cs[k][0] & S.cw[k][0], s_hi = S.cs[k][1] & S.cw[k][1];
+                const uint32_t w_lo = S.cs[k][0] & ~S.cw[k][0], w_hi = S.cs[k][1] & ~S.cw[k][1];
+                strong[o] = (u64)s_lo | ((u64)s_hi << 32);
+                weak[o] = (u64)w_lo | ((u64)w_hi << 32);
+                n_strong += __popc(s_lo) + __popc(s_hi);
+                n_weak += __popc(w_lo) + __popc(w_hi);
             }
         }
     }
