@@ -773,7 +773,7 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
 }
 
 // round 0: every tile.  grid = ceil(n_tiles / 4), block = 256 (4 independent waves)
-__global__ __launch_bounds__(256) void k_canny_hyst_all(hyst_args A, unsigned n_tiles)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_canny_hyst_all(hyst_args A, unsigned n_tiles)
 {
     const unsigned tile = blockIdx.x * 4 + wave_id();
     if (tile < n_tiles) relax_tile(A, tile);

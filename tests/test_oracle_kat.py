@@ -355,3 +355,25 @@ def test_oracle_regression_pins():
                 assert abs(a[k] - v) <= 1e-9 * abs(v) + 1e-12, (b["name"], k, a[k], v)
             else:
                 assert a[k] == v, (b["name"], k, a[k], v)
+
+
+@pytest.mark.parametrize("case,pair,straddles", [(40610, 0, True), (40610, 1, False), (41571, 0, True), (5, 0, False)])
+def test_farneback_restatements_and_the_border_discontinuity(case, pair, straddles):
+    """C oracle (OpenCV's float/double mix and FarnebackUpdateFlow_Blur's sliding sums) against the float64 NumPy
+    restatement: 1e-6 agreement in general; on the two frames the round-2 fuzzer found, a top-row pixel's vertical
+    flow is within 6e-8 of the in-frame test of FarnebackUpdateMatrices and the two evaluations fall on different sides
+    (4.1e-4 on the mean of so small a frame) - see tests/test_gpu_parity.py::test_farneback_border_discontinuity_cases."""
+    from rtvqa_amd import synth
+    r = np.random.default_rng(case)
+    h, w = int(r.integers(1, 200)), int(r.integers(1, 320))
+    kind, n = int(r.integers(0, 3)), int(r.integers(1, 4))
+    if kind == 0:
+        fr = r.integers(0, 256, (n + 1, h, w, 3), dtype=np.uint8)
+    elif kind == 1:
+        fr = synth.s_natural(n + 1, h, w, seed=case)
+    else:
+        fr = np.repeat(r.integers(0, 256, (n + 1, (h + 7) // 8, (w + 7) // 8, 3), dtype=np.uint8), 8, axis=1).repeat(8, axis=2)[:, :h, :w]
+    g, gp = co.bgr2gray(fr[pair + 1]), co.bgr2gray(fr[pair])
+    a, b = co.farneback(gp, g), no.farneback_mean_mag(gp, g)
+    rel = abs(a - b) / b
+    assert (1e-4 < rel < 2e-3) if straddles else rel < 2e-6
