@@ -757,17 +757,24 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     const bool Uf = __any(lane == 0 && (ecs & pd) != 0), Df = __any(lane == 63 && (ecs & pd) != 0);
     const bool ULf = __any(lane == 0 && (ecl & pb0) != 0), URf = __any(lane == 0 && (ecr & pb63) != 0);
     const bool DLf = __any(lane == 63 && (ecl & pb0) != 0), DRf = __any(lane == 63 && (ecr & pb63) != 0);
-    if (lane == 0) {
-        const bool nbr[8] = {ULf, Uf, URf, L, R, DLf, Df, DRf};
-        const int dys[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, dxs[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            if (!nbr[b]) continue;
-            const int ty2 = ty + dys[b], tx2 = tx + dxs[b];
-            if (ty2 < 0 || ty2 >= A.tiles_y || tx2 < 0 || tx2 >= A.ww) continue;
-            const unsigned t2 = (unsigned)((f * A.tiles_y + ty2) * A.ww + tx2);
-            if (atomicExch(&A.queued[t2], 1u) == 0u)
-                A.out_list[(unsigned)f * (unsigned)(A.tiles_y * A.ww) + atomicAdd(&A.out_count[f], 1u)] = t2;
+    // Wake the neighbours: lanes 0..7 take one neighbour each (their dedup atomics overlap), then ONE append-counter
+    // atomic per tile reserves the list slots.  The per-frame counter is a single address: at 2160p (64 frames, 2040
+    // tiles each) one atomicAdd per enqueued neighbour serialised in L2 and made round 0 twice as slow as at 1080p for
+    // the same tile count and the same 16-17 relaxation steps per tile.
+    const unsigned nbmask = (ULf ? 1u : 0u) | (Uf ? 2u : 0u) | (URf ? 4u : 0u) | (L ? 8u : 0u) | (R ? 16u : 0u) |
+                            (DLf ? 32u : 0u) | (Df ? 64u : 0u) | (DRf ? 128u : 0u);
+    if (nbmask) { // wave-uniform
+        const int b = lane & 7;
+        const int ty2 = ty + (int)((0xA940u >> (2 * b)) & 3u) - 1, tx2 = tx + (int)((0x9224u >> (2 * b)) & 3u) - 1;
+        const bool want = lane < 8 && ((nbmask >> b) & 1u) && ty2 >= 0 && ty2 < A.tiles_y && tx2 >= 0 && tx2 < A.ww;
+        const unsigned t2 = (unsigned)((f * A.tiles_y + ty2) * A.ww + tx2);
+        const bool got = want && atomicExch(&A.queued[t2], 1u) == 0u;
+        const u64 gm = __ballot(got);
+        if (gm) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&A.out_count[f], (unsigned)__popcll(gm));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (got) A.out_list[(unsigned)f * (unsigned)(A.tiles_y * A.ww) + base + (unsigned)__popcll(gm & ((1ull << lane) - 1ull))] = t2;
         }
     }
 }
