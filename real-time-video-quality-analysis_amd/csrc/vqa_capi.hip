@@ -702,18 +702,19 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         if (rc) return rc;
         rc = ensure(c, c->tile_flags, sizeof(uint32_t) * ntiles * 2); // dedup flags, one array per work list
         if (rc) return rc;
-        rc = ensure(c, c->dirty0, sizeof(uint32_t) * ntiles);     // work list A
+        const size_t NS = CANNY_HYST_SEGMENTS; // list segments (and append counters) per frame
+        rc = ensure(c, c->dirty0, sizeof(uint32_t) * ntiles * NS); // work list A
         if (rc) return rc;
-        rc = ensure(c, c->dirty1, sizeof(uint32_t) * ntiles);     // work list B
+        rc = ensure(c, c->dirty1, sizeof(uint32_t) * ntiles * NS); // work list B
         if (rc) return rc;
-        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 2 * n);   // per-frame append counters of the two lists
+        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 2 * n * NS); // append counters of the two lists
         if (rc) return rc;
         unsigned long long *strong = (unsigned long long *)c->state.p, *weak = strong + words;
         unsigned *queued[2] = {(unsigned *)c->tile_flags.p, (unsigned *)c->tile_flags.p + ntiles};
         unsigned *lists[2] = {(unsigned *)c->dirty0.p, (unsigned *)c->dirty1.p};
         unsigned *counts = (unsigned *)c->again_dev.p;
         HIPCHK(c, hipMemsetAsync(queued[0], 0, sizeof(uint32_t) * ntiles * 2, st));
-        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * n, st));
+        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * n * NS, st));
         int lo = P.canny_low, hi = P.canny_high;
         if (lo > hi) { int t = lo; lo = hi; hi = t; }
         {
@@ -725,7 +726,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         int round = 0;
         {
             prof_scope ps_(c, VQA_K_CANNY_HYST);
-            launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], counts + n, res);
+            launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], counts + n * NS, res);
         }
         {
             // rounds 1..WIDE (still many tiles): wide grid over the per-frame lists; then the tail kernel
@@ -737,11 +738,11 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             if (const char *e = getenv("VQA_HYST_WIDE")) WIDE = atoi(e) > 0 ? atoi(e) : WIDE; // tuning knob
             for (round = 1; round <= WIDE; round++) {
                 const int in = round & 1, out = in ^ 1;
-                HIPCHK(c, hipMemsetAsync(counts + out * n, 0, sizeof(uint32_t) * n, st));
-                launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in * n,
-                                       queued[out], lists[out], counts + out * n, res);
+                HIPCHK(c, hipMemsetAsync(counts + out * n * NS, 0, sizeof(uint32_t) * n * NS, st));
+                launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in * n * NS,
+                                       queued[out], lists[out], counts + out * n * NS, res);
             }
-            launch_canny_hyst_tail(st, strong, weak, n, ph, pw, lists[0], counts, queued[0], lists[1], counts + n,
+            launch_canny_hyst_tail(st, strong, weak, n, ph, pw, lists[0], counts, queued[0], lists[1], counts + n * NS,
                                    queued[1], round & 1, res);
         }
         launch_canny_finish(st, strong, n, ph, pw, res);

@@ -42,6 +42,7 @@ void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t pl
 // hysteresis on the strong/weak bit-planes: round 0 visits every 64x64 tile, later rounds the
 // tiles a neighbour enqueued (compact list + dedup flags); *out_count must be 0 at launch.
 unsigned canny_hyst_tiles(int n, int h, int w);
+constexpr int CANNY_HYST_SEGMENTS = 16; // work-list segments per frame (k_canny.hip: HSEG)
 void launch_canny_hyst_all(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                            int w, unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res);
 void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
