@@ -220,7 +220,12 @@ VQA_API int vqa_comm_unique_id(void *id, size_t id_bytes);
 VQA_API int vqa_comm_create_rank(vqa_ctx *ctx, const void *id, size_t id_bytes, int n_ranks, int rank, vqa_comm **out);
 VQA_API int vqa_comm_destroy(vqa_comm *comm);
 VQA_API int vqa_comm_size(const vqa_comm *comm);           /* ranks in the communicator */
-VQA_API const char *vqa_comm_last_error(const vqa_comm *comm);
+VQA_API const char *vqa_comm_last_error(const vqa_comm *comm); /* comm == NULL: why this thread's last creation failed */
+/* Test seam.  With VQA_COMM_FAKE_RCCL=1 in the environment an in-library stand-in takes the place of the RCCL entry
+ * points (it checks the group bracketing and sums on the host), which lets the single-process multi-context path run
+ * on a one-GPU box; this returns the stand-in's call trace ("" otherwise).  Multi-device use over real RCCL has not
+ * run on hardware yet (no multi-GPU box was available to the builder).                                              */
+VQA_API const char *vqa_comm_debug_trace(void);
 /* In place: vals is [local contexts][count] doubles, row i belongs to the i-th local
  * context (one row with vqa_comm_create_rank); on return every row holds the sum over
  * ALL ranks.  count <= 64.  Blocking; runs on the contexts' streams.                   */

@@ -108,6 +108,7 @@ SIGNATURES = {
     "vqa_comm_destroy": (C.c_int, [C.c_void_p]),
     "vqa_comm_size": (C.c_int, [C.c_void_p]),
     "vqa_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "vqa_comm_debug_trace": (C.c_char_p, []),
     "vqa_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
 }
 

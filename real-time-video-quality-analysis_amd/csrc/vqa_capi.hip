@@ -605,8 +605,10 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
 
     // Frames ride in gridDim.y (<= 65535): larger batches are enqueued as consecutive slices on the same stream.  A
     // slice's "previous frame" is the last frame of the slice before it; scratch planes are reused (stream order).
+    // A slice that fails after earlier slices were enqueued must not hand the buffers back while their kernels are in
+    // flight (pend_c stays 0, so the caller could resubmit or free them): the loop drains the stream before it returns.
     const int SLICE = 32768;
-    for (int a0 = 0; a0 < n_all; a0 += SLICE) {
+    auto run_slice = [&](const int a0) -> int {
     const int n = n_all - a0 < SLICE ? n_all - a0 : SLICE;
     const uint8_t *dframes = dframes_all + (int64_t)a0 * frame_stride;
     const uint8_t *dprev = a0 ? dframes_all + (int64_t)(a0 - 1) * frame_stride : dprev_all;
@@ -758,7 +760,15 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         launch_orb64(st, dframes, n, h, w, frame_stride, row_stride, T64.xofs, T64.xa, T64.yofs, T64.yb, T64.mode, res);
     }
     c->last_n = n; c->last_has_full = need_full; c->last_has_planes = need_planes; // (debug planes show the last slice)
-    } // slices
+    return VQA_OK;
+    }; // run_slice
+    for (int a0 = 0; a0 < n_all; a0 += SLICE) {
+        const int src = run_slice(a0);
+        if (src) {
+            if (a0 > 0) (void)hipStreamSynchronize(st);
+            return src;
+        }
+    }
     const bool has_prev0 = batch_has_prev0;
 
     HIPCHK(c, hipGetLastError());
@@ -809,6 +819,10 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
         if (d.width <= 0 || d.height <= 0 || d.offset < 0 || d.pixel_step <= 0 ||
             d.row_stride < (int64_t)d.width * d.pixel_step - (d.pixel_step - 1))
             return VQA_ERR_INVALID;
+        // k_ssim_gauss addresses a strip's rows through a 32-bit scalar buffer offset (row * row_stride) plus a 32-bit
+        // lane offset: a plane whose rows span 2 GiB (absurd strides / regions of interest only) would wrap silently
+        if (ssim_mode == VQA_SSIM_GAUSS &&
+            (int64_t)d.height * d.row_stride + (int64_t)d.width * d.pixel_step >= ((int64_t)1 << 31)) return VQA_ERR_UNSUPPORTED;
         if (ssim_mode == VQA_SSIM_GAUSS && (d.width < 11 || d.height < 11)) return VQA_ERR_UNSUPPORTED;
         if (ssim_mode == VQA_SSIM_FFMPEG && (d.width < 8 || d.height < 8)) return VQA_ERR_UNSUPPORTED;
         const int64_t end = d.offset + (int64_t)(d.height - 1) * d.row_stride + (int64_t)(d.width - 1) * d.pixel_step + 1;

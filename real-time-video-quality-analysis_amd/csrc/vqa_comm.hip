@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,31 +36,120 @@ struct rccl_api {
     bool ok = false;
 };
 
+// ---- test seam (VQA_COMM_FAKE_RCCL=1): an in-library stand-in for the seven RCCL entry points, so that the
+// SINGLE-PROCESS MULTI-CONTEXT path (device list, one scratch buffer per context on its own device, staging copies,
+// group start/end bracketing, row layout of vals) can be exercised on a box with one GPU, where RCCL itself refuses
+// two ranks on one device.  The fake checks the bracketing, sums on the host, and records every call in a trace
+// (vqa_comm_debug_trace).  It is never selected unless the environment variable is set.
+struct fake_comm { int rank, nranks, dev; };
+struct fake_pending { const void *send; void *recv; size_t count; fake_comm *comm; hipStream_t st; };
+static std::vector<fake_pending> g_fake_pending;
+static bool g_fake_in_group = false;
+static std::string g_fake_trace;
+
+static ncclResult_t fake_GetUniqueId(ncclUniqueId *u) { memset(u, 0x5a, sizeof *u); g_fake_trace += "GetUniqueId;"; return ncclSuccess; }
+static ncclResult_t fake_CommInitAll(ncclComm_t *comms, int n, const int *devs)
+{
+    g_fake_trace += "CommInitAll(n=" + std::to_string(n) + ",devs=";
+    for (int i = 0; i < n; i++) {
+        comms[i] = (ncclComm_t) new fake_comm{i, n, devs[i]};
+        g_fake_trace += std::to_string(devs[i]) + (i + 1 < n ? "," : "");
+    }
+    g_fake_trace += ");";
+    return ncclSuccess;
+}
+static ncclResult_t fake_CommInitRank(ncclComm_t *comm, int n, ncclUniqueId, int rank)
+{
+    if (n != 1) return ncclInvalidUsage; // the fake has no second process to meet
+    *comm = (ncclComm_t) new fake_comm{rank, n, -1};
+    g_fake_trace += "CommInitRank(n=1);";
+    return ncclSuccess;
+}
+static ncclResult_t fake_CommDestroy(ncclComm_t c) { delete (fake_comm *)c; g_fake_trace += "CommDestroy;"; return ncclSuccess; }
+static ncclResult_t fake_GroupStart()
+{
+    if (g_fake_in_group) return ncclInvalidUsage;
+    g_fake_in_group = true;
+    g_fake_pending.clear();
+    g_fake_trace += "GroupStart;";
+    return ncclSuccess;
+}
+static ncclResult_t fake_AllReduce(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm,
+                                   hipStream_t st)
+{
+    if (!g_fake_in_group || dt != ncclFloat64 || op != ncclSum) return ncclInvalidUsage; // must sit inside a group
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, recv) != hipSuccess) return ncclInvalidArgument;
+    fake_comm *fc = (fake_comm *)comm;
+    g_fake_trace += "AllReduce(rank=" + std::to_string(fc->rank) + ",count=" + std::to_string(count) + ",buf_dev=" +
+                    std::to_string(at.device) + ");";
+    g_fake_pending.push_back({send, recv, count, fc, st});
+    return ncclSuccess;
+}
+static ncclResult_t fake_GroupEnd()
+{
+    if (!g_fake_in_group) return ncclInvalidUsage;
+    g_fake_in_group = false;
+    g_fake_trace += "GroupEnd(" + std::to_string(g_fake_pending.size()) + ");";
+    if (g_fake_pending.empty()) return ncclSuccess;
+    if ((int)g_fake_pending.size() != g_fake_pending[0].comm->nranks) return ncclInvalidUsage; // every rank must take part
+    const size_t count = g_fake_pending[0].count;
+    std::vector<double> sum(count, 0.0), tmp(count);
+    for (auto &p : g_fake_pending) {
+        if (p.count != count || hipStreamSynchronize(p.st) != hipSuccess) return ncclInvalidUsage;
+        if (hipMemcpy(tmp.data(), p.send, sizeof(double) * count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+        for (size_t i = 0; i < count; i++) sum[i] += tmp[i];
+    }
+    for (auto &p : g_fake_pending)
+        if (hipMemcpy(p.recv, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    return ncclSuccess;
+}
+static const char *fake_GetErrorString(ncclResult_t r) { return r == ncclSuccess ? "ok" : "fake rccl: invalid usage"; }
+
+static bool fake_mode()
+{
+    const char *e = getenv("VQA_COMM_FAKE_RCCL");
+    return e && e[0] == '1';
+}
+
+// Thread-safe by construction: a function-local static initialised once by the lambda (C++11 magic statics), so two
+// host threads creating communicators at the same time can never see a half-filled table.
 rccl_api &rccl()
 {
-    static rccl_api a;
-    static bool tried = false;
-    if (tried) return a;
-    tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-        a.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (a.h) break;
-    }
-    if (!a.h) return a;
-#define SYM(field, name) a.field = (decltype(a.field))dlsym(a.h, name)
-    SYM(GetUniqueId, "ncclGetUniqueId");
-    SYM(CommInitAll, "ncclCommInitAll");
-    SYM(CommInitRank, "ncclCommInitRank");
-    SYM(CommDestroy, "ncclCommDestroy");
-    SYM(AllReduce, "ncclAllReduce");
-    SYM(GroupStart, "ncclGroupStart");
-    SYM(GroupEnd, "ncclGroupEnd");
-    SYM(GetErrorString, "ncclGetErrorString");
+    static rccl_api a = [] {
+        rccl_api t;
+        if (fake_mode()) {
+            t.GetUniqueId = fake_GetUniqueId; t.CommInitAll = fake_CommInitAll; t.CommInitRank = fake_CommInitRank;
+            t.CommDestroy = fake_CommDestroy; t.AllReduce = fake_AllReduce; t.GroupStart = fake_GroupStart;
+            t.GroupEnd = fake_GroupEnd; t.GetErrorString = fake_GetErrorString;
+            t.ok = true;
+            return t;
+        }
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            t.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (t.h) break;
+        }
+        if (!t.h) return t;
+#define SYM(field, name) t.field = (decltype(t.field))dlsym(t.h, name)
+        SYM(GetUniqueId, "ncclGetUniqueId");
+        SYM(CommInitAll, "ncclCommInitAll");
+        SYM(CommInitRank, "ncclCommInitRank");
+        SYM(CommDestroy, "ncclCommDestroy");
+        SYM(AllReduce, "ncclAllReduce");
+        SYM(GroupStart, "ncclGroupStart");
+        SYM(GroupEnd, "ncclGroupEnd");
+        SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
-    a.ok = a.GetUniqueId && a.CommInitAll && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GroupStart && a.GroupEnd;
+        t.ok = t.GetUniqueId && t.CommInitAll && t.CommInitRank && t.CommDestroy && t.AllReduce && t.GroupStart && t.GroupEnd;
+        return t;
+    }();
     return a;
 }
+
+// why the last vqa_comm_create / vqa_comm_create_rank of this thread failed (the communicator object does not
+// survive a failed creation, so its own last_err cannot say): read with vqa_comm_last_error(NULL)
+thread_local std::string g_create_err;
 } // namespace
 
 struct vqa_comm {
@@ -100,10 +190,13 @@ int vqa_comm_create(vqa_ctx *const *ctxs, int n_ctx, vqa_comm **out)
     if (!ctxs || n_ctx <= 0 || !out) return VQA_ERR_INVALID;
     for (int i = 0; i < n_ctx; i++) {
         if (!ctxs[i]) return VQA_ERR_INVALID;
-        for (int j = 0; j < i; j++)
-            if (vqa_ctx_device_(ctxs[i]) == vqa_ctx_device_(ctxs[j])) return VQA_ERR_INVALID; // one ctx per device
+        for (int j = 0; j < i; j++) // one ctx per device (the test seam alone may put two on one: it never calls RCCL)
+            if (vqa_ctx_device_(ctxs[i]) == vqa_ctx_device_(ctxs[j]) && !fake_mode()) {
+                g_create_err = "vqa_comm_create: two contexts on device " + std::to_string(vqa_ctx_device_(ctxs[i]));
+                return VQA_ERR_INVALID;
+            }
     }
-    if (!rccl().ok) return VQA_ERR_UNSUPPORTED; // librccl.so.1 not installed
+    if (!rccl().ok) { g_create_err = "librccl.so.1 could not be loaded"; return VQA_ERR_UNSUPPORTED; }
     vqa_comm *c = new vqa_comm;
     c->ctxs.assign(ctxs, ctxs + n_ctx);
     c->comms.resize(n_ctx);
@@ -111,7 +204,11 @@ int vqa_comm_create(vqa_ctx *const *ctxs, int n_ctx, vqa_comm **out)
     std::vector<int> devs(n_ctx);
     for (int i = 0; i < n_ctx; i++) devs[i] = vqa_ctx_device_(ctxs[i]);
     const ncclResult_t r = rccl().CommInitAll(c->comms.data(), n_ctx, devs.data());
-    if (r != ncclSuccess) { delete c; return VQA_ERR_HIP; }
+    if (r != ncclSuccess) {
+        g_create_err = std::string("ncclCommInitAll -> ") + (rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
+        delete c;
+        return VQA_ERR_HIP;
+    }
     const int rc = alloc_scratch(c);
     if (rc) { vqa_comm_destroy(c); return rc; }
     *out = c;
@@ -132,7 +229,7 @@ int vqa_comm_unique_id(void *id, size_t id_bytes)
 int vqa_comm_create_rank(vqa_ctx *ctx, const void *id, size_t id_bytes, int n_ranks, int rank, vqa_comm **out)
 {
     if (!ctx || !id || id_bytes < VQA_COMM_ID_BYTES || n_ranks <= 0 || rank < 0 || rank >= n_ranks || !out) return VQA_ERR_INVALID;
-    if (!rccl().ok) return VQA_ERR_UNSUPPORTED;
+    if (!rccl().ok) { g_create_err = "librccl.so.1 could not be loaded"; return VQA_ERR_UNSUPPORTED; }
     if (hipSetDevice(vqa_ctx_device_(ctx)) != hipSuccess) return VQA_ERR_HIP;
     vqa_comm *c = new vqa_comm;
     c->ctxs.push_back(ctx);
@@ -141,7 +238,11 @@ int vqa_comm_create_rank(vqa_ctx *ctx, const void *id, size_t id_bytes, int n_ra
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     const ncclResult_t r = rccl().CommInitRank(&c->comms[0], n_ranks, u, rank);
-    if (r != ncclSuccess) { delete c; return VQA_ERR_HIP; }
+    if (r != ncclSuccess) {
+        g_create_err = std::string("ncclCommInitRank -> ") + (rccl().GetErrorString ? rccl().GetErrorString(r) : "rccl error");
+        delete c;
+        return VQA_ERR_HIP;
+    }
     const int rc = alloc_scratch(c);
     if (rc) { vqa_comm_destroy(c); return rc; }
     *out = c;
@@ -163,7 +264,10 @@ int vqa_comm_destroy(vqa_comm *c)
 
 int vqa_comm_size(const vqa_comm *c) { return c ? c->nranks : VQA_ERR_INVALID; }
 
-const char *vqa_comm_last_error(const vqa_comm *c) { return c ? c->last_err.c_str() : ""; }
+const char *vqa_comm_last_error(const vqa_comm *c) { return c ? c->last_err.c_str() : g_create_err.c_str(); }
+
+// the calls the test seam received, in order ("" unless VQA_COMM_FAKE_RCCL=1)
+const char *vqa_comm_debug_trace(void) { return g_fake_trace.c_str(); }
 
 // vals: [local contexts][count] doubles, row i belongs to the i-th local context; in place.
 int vqa_allreduce(vqa_comm *c, double *vals, int count)

@@ -1,7 +1,7 @@
-# After `gpurun -- bash scripts/gpu_round_end.sh`: copy the judged summaries from gpurun_out/ (scratch) into
-# profiles/ (tracked).  usage: bash scripts/collect_profiles.sh [round_tag, default round2]
+# After `gpurun -- bash scripts/gpu_round_end.sh <round>`: copy the judged summaries from gpurun_out/ (scratch) into
+# profiles/ (tracked).  usage: bash scripts/collect_profiles.sh [round_tag, default round3]
 set -e
-R=${1:-round2}
+R=${1:-round3}
 cd "$(dirname "$0")/.."
 for t in c2 c3 c2ff c4 c3fb c3noise; do
   f=$(ls -t gpurun_out/prof_final_$t/*/*kernel_stats.csv 2>/dev/null | head -1)
@@ -9,8 +9,8 @@ for t in c2 c3 c2ff c4 c3fb c3noise; do
   [ -f gpurun_out/bench_final_$t.log ] && tail -1 gpurun_out/bench_final_$t.log > profiles/${R}_${t}_bench.json
 done
 for t in c2 c3 c4; do
-  [ -f gpurun_out/final_${t}_pmc.json ] && sed "s/\"tag\": \"final_/\"tag\": \"${R}_/" gpurun_out/final_${t}_pmc.json > profiles/${R}_${t}_pmc.json
+  [ -f gpurun_out/${R}_${t}_pmc.json ] && cp gpurun_out/${R}_${t}_pmc.json profiles/${R}_${t}_pmc.json
 done
-[ -f gpurun_out/final_c3_valu.json ] && sed "s/\"tag\": \"final_/\"tag\": \"${R}_/" gpurun_out/final_c3_valu.json > profiles/${R}_c3_valu.json
-rm -f profiles/final_*
-ls -la profiles/
+[ -f gpurun_out/${R}_c3_valu.json ] && cp gpurun_out/${R}_c3_valu.json profiles/${R}_c3_valu.json
+[ -f gpurun_out/clock_trace.json ] && cp gpurun_out/clock_trace.json profiles/${R}_c3_clock.json
+ls -la profiles/ | grep ${R}

@@ -175,6 +175,7 @@ def test_allreduce_over_rccl_single_device():
         N.check(lib.vqa_comm_destroy(comm), "vqa_comm_destroy")
         two = (C.c_void_p * 2)(ctx, ctx)
         assert lib.vqa_comm_create(two, 2, C.byref(comm)) == N.VQA_ERR_INVALID  # one ctx per device
+        assert b"two contexts on device 0" in lib.vqa_comm_last_error(None)     # a failed creation says why
         uid = (C.c_char * 128)()
         N.check(lib.vqa_comm_unique_id(uid, 128), "vqa_comm_unique_id")
         N.check(lib.vqa_comm_create_rank(ctx, uid, 128, 1, 0, C.byref(comm)), "vqa_comm_create_rank")
@@ -184,3 +185,48 @@ def test_allreduce_over_rccl_single_device():
         N.check(lib.vqa_comm_destroy(comm), "vqa_comm_destroy")
     finally:
         lib.vqa_destroy(ctx)
+
+
+_SEAM_SCRIPT = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r)
+from rtvqa_amd import _native as N
+lib = N.load()
+ctxs = []
+for _ in range(3):
+    c = C.c_void_p()
+    N.check(lib.vqa_create(0, C.byref(c)), "vqa_create")
+    ctxs.append(c)
+comm = C.c_void_p()
+arr = (C.c_void_p * 3)(*ctxs)
+N.check(lib.vqa_comm_create(arr, 3, C.byref(comm)), "vqa_comm_create")
+vals = (C.c_double * 6)(1.0, 2.0, 10.0, 20.0, 100.0, 200.0)   # [3 contexts][2]
+N.check(lib.vqa_allreduce(comm, vals, 2), "vqa_allreduce")
+size = lib.vqa_comm_size(comm)
+N.check(lib.vqa_comm_destroy(comm), "vqa_comm_destroy")
+for c in ctxs:
+    lib.vqa_destroy(c)
+print(json.dumps({"vals": list(vals), "size": size, "trace": lib.vqa_comm_debug_trace().decode()}))
+"""
+
+
+@pytest.mark.gpu
+def test_multi_context_allreduce_through_the_test_seam():
+    """vqa_comm_create with n_ctx > 1 (single process, one context per device: SURVEY 8e's ncclCommInitAll design) has
+    never had two devices to run on.  With VQA_COMM_FAKE_RCCL=1 an in-library stand-in replaces the RCCL entry points, so
+    everything AROUND them runs on the one GPU of the test box: the device list handed to CommInitAll, one scratch buffer
+    per context on its device, the H2D staging of each context's row, group start / one AllReduce per context / group
+    end, the D2H of every row.  The stand-in refuses an AllReduce outside a group or a group that lacks a rank."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, VQA_COMM_FAKE_RCCL="1")
+    out = subprocess.run([sys.executable, "-c", _SEAM_SCRIPT % REPO], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["vals"] == [111.0, 222.0] * 3 and got["size"] == 3
+    t = got["trace"]
+    assert t.startswith("CommInitAll(n=3,devs=0,0,0);GroupStart;")
+    assert [t.count("AllReduce(rank=%d,count=2,buf_dev=0);" % r) for r in range(3)] == [1, 1, 1]
+    assert t.index("GroupStart;") < t.index("AllReduce(rank=0") < t.index("AllReduce(rank=2") < t.index("GroupEnd(3);")
+    assert t.count("CommDestroy;") == 3
