@@ -39,22 +39,24 @@ def test_default_workload_is_the_headline_config():
     assert CONTRACT_KEYS <= set(line)
 
 
-def test_world2_gloo_rank_logic_json_shape():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_rank_logic_json_shape(world):
+    """The N > 1 rank logic at world 2 and at the node's full width (8): one rank per GPU as the driver launches it."""
     port = _free_port()
-    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-              "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
-              "--stub-engine"])
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+              "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1",
+              "--backend", "gloo", "--stub-engine"])
     assert r.returncode == 0, r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints exactly ONE JSON line"
     line = json.loads(lines[0])
     assert CONTRACT_KEYS <= set(line)
-    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["n_gpus"] == world and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
     cfg = line["config"]
     assert cfg["collective"] == "gloo scalar all-reduce" and cfg["rccl_ranks"] is None
-    assert cfg["devices"] == [0, 1] and cfg["parallelism"] == "1 stream/GPU x2"
-    # whole-job aggregate: frames of BOTH ranks over the max-over-ranks time
-    frames = cfg["frames_per_step_per_gpu"] * line["steps"] * 2
+    assert cfg["devices"] == list(range(world)) and cfg["parallelism"] == "1 stream/GPU x%d" % world
+    # whole-job aggregate: frames of ALL ranks over the max-over-ranks time
+    frames = cfg["frames_per_step_per_gpu"] * line["steps"] * world
     assert abs(line["value"] - frames / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-3 * line["value"]
 
 

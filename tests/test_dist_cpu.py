@@ -102,7 +102,9 @@ def _sharded_worker(rank, world, port, clip, interval, out_path):
 def test_sharded_scene_complexity_equals_single_process(tmp_path):
     from oracle import pipeline as pl
     rng = np.random.default_rng(11)
-    for n, interval, world in ((75, 10, 2), (41, 5, 3), (15, 10, 2), (25, 10, 2)):
+    # (world 8 = the node's width: 75/10 leaves two ranks with one sample and six with none of the temporal series'
+    # tail; 41/10 gives 3 samples to 8 ranks, so five ranks hold nothing and still take part in the reduction)
+    for n, interval, world in ((75, 10, 2), (41, 5, 3), (15, 10, 2), (25, 10, 2), (75, 10, 8), (41, 10, 8)):
         clip = rng.integers(0, 256, (n, 40, 56, 3), dtype=np.uint8)
         clip[:, 18:22, 26:30] = 255  # something for the corner detector at the thumbnail's centre
         out = str(tmp_path / ("r%d_%%d.npy" % n))
