@@ -328,8 +328,9 @@ __global__ __launch_bounds__(64) void k_canny_nms2(const uint8_t *__restrict__ g
 // produces its operand misses the wait states gfx950 needs between a DOT result and its first VALU use and reads a
 // stale register (measured: wrong magnitudes whose pattern changed with unrelated code edits).
 __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return (max(a, b) - min(a, b)) + c; }
-__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x13C, 0xf, 0xf, false); }
-__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x134, 0xf, 0xf, false); }
+// (mov_dpp: every lane has a source lane in a rotation, so there is no "old" value to pre-load into the destination)
+__device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134, 0xf, 0xf, false); }
 
 // lane `lane` of `old` <- the wave-uniform `val`.  The lane select goes through M0: a VOP3 on gfx9 reads at most one
 // SGPR besides it.  (M0 is otherwise unused here: these kernels have no LDS / GDS traffic.)
@@ -398,19 +399,15 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const __amdgpu_b
         const uint32_t gxb = S.s[PH ^ 1][g] + s;          // gx + 1024, always positive
         const uint32_t a = sad_u32(gxb, 1024u, zero);     // |gx| (zero: an opaque 0, the + 0 would be folded and the pattern lost)
         const uint32_t h2a = S.h2[PH][g];                 // row R-2 (same parity as R)
-        mnew[g] = sad_u32(h2, h2a, a) & cmask[g];         // |gx| + |gy|, 0 outside the image's columns
+        // |gx| + |gy|, 0 outside the image's columns (an interior wave has no such column: its halo group's unused
+        // lanes repeat a valid column and are never read)
+        mnew[g] = EDGE ? (sad_u32(h2, h2a, a) & cmask[g]) : sad_u32(h2, h2a, a);
         __builtin_assume(a <= 1020u);
         if (g < 4) {
             ax[g] = a;
             opp[g] = __ballot(gxb < 1024u) ^ __ballot(h2 < h2a); // (gx ^ gy) < 0: gx < 0 differs from gy < 0
         }
         S.h1[PH][g] = h1; S.s[PH][g] = s; S.h2[PH][g] = h2;
-    }
-    if (!row_in) { // rows -1 and h: a real (wave-uniform) branch, the asm keeps it from becoming five selects per row.
-        // The s_nop supplies the two wait states a DPP read needs after a vector write: the hazard recognizer does
-        // not look inside an asm statement (see sad_u32)
-#pragma unroll
-        for (int g = 0; g < 5; g++) asm volatile("v_mov_b32 %0, 0\n\ts_nop 1" : "=v"(mnew[g]));
     }
 #ifndef NMS3_PROBE
 #define NMS3_PROBE 0   // measurement builds only (scripts/build_probes.sh): 1 no capture, 2 no decisions, 3 no neighbours either
@@ -426,6 +423,15 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const __amdgpu_b
         S.m[PH][0] = mnew[0]; S.m[PH][1] = mnew[1]; S.m[PH][2] = mnew[2]; S.m[PH][3] = mnew[3];
         S.mL[PH][0] = lane0 ? rH : r0; S.mL[PH][1] = lane0 ? r0 : r1; S.mL[PH][2] = lane0 ? r1 : r2; S.mL[PH][3] = lane0 ? r2 : r3;
         S.mR[PH][0] = lane63 ? l1 : l0; S.mR[PH][1] = lane63 ? l2 : l1; S.mR[PH][2] = lane63 ? l3 : l2; S.mR[PH][3] = lane63 ? lH : l3;
+        if (!row_in) { // rows -1 and h have magnitude 0.  A real (wave-uniform) branch taken twice per frame column: the asm
+                       // keeps the optimiser from turning it into twelve selects on every row ("+v": no copies either)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                asm volatile("v_mov_b32 %0, 0" : "+v"(S.m[PH][k]));
+                asm volatile("v_mov_b32 %0, 0" : "+v"(S.mL[PH][k]));
+                asm volatile("v_mov_b32 %0, 0" : "+v"(S.mR[PH][k]));
+            }
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) { S.m[PH][k] = mnew[k] + mnew[4]; S.cs[k][0] += S.m[PH][k] + ax[k] + (uint32_t)opp[k]; }
