@@ -818,8 +818,12 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
 // round 0: every tile.  grid = ceil(n_tiles / 4), block = 256 (4 independent waves)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_canny_hyst_all(hyst_args A, unsigned n_tiles)
 {
-    const unsigned tile = blockIdx.x * 4 + wave_id();
-    if (tile < n_tiles) relax_tile(A, tile);
+    // XCD-aware: XCD c (= workgroup id % 8) walks the contiguous tile range [c * per, (c + 1) * per) * 4, so a tile and
+    // the neighbours whose rows it reads as its halo sit behind one L2
+    const unsigned per = (gridDim.x + 7u) >> 3;
+    const unsigned wg = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const unsigned tile = wg * 4 + wave_id();
+    if ((blockIdx.x >> 3) < per && tile < n_tiles) relax_tile(A, tile);
 }
 
 // later rounds: the tiles some neighbour enqueued in the previous round
@@ -962,7 +966,7 @@ void launch_canny_hyst_all(hipStream_t st, unsigned long long *strong, const uns
 {
     if (n <= 0) return;
     const unsigned nt = canny_hyst_tiles(n, h, w);
-    hipLaunchKernelGGL(k_canny_hyst_all, dim3((nt + 3) / 4), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_canny_hyst_all, dim3(8 * (((nt + 3) / 4 + 7) / 8)), dim3(256), 0, st,
                        make_hyst_args(strong, weak, h, w, queued, out_list, out_count, res), nt);
 }
 
