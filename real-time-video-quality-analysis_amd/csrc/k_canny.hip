@@ -5,24 +5,27 @@
 //
 // Stage 1 — gradient, non-maximum suppression, double threshold.  Output: two BIT-PLANES (edge,
 //   weak candidate), one u64 per 64 pixels, 2 x P/8 bytes instead of a P-byte map.
-//   k_canny_nms2 (default): register-rolling, 4 pixels per lane, packed 16-bit Sobel, no LDS (see below).
-//   k_canny_nms  (VQA_NMS_VARIANT=1, the first version, kept for A/B): 64x32 tile per workgroup, gray
-//   tile + 2-pixel replicated halo staged in LDS, magnitudes through LDS, words built with __ballot.
-//   Both: Sobel 3x3 on replicated borders, L1 magnitude = 0 outside the image (OpenCV's zero-bordered
+//   k_canny_nms3 (default): lane = column; a vector compare of 64 columns IS a bit-plane word and every NMS decision is
+//     mask logic on the scalar unit; one unaligned dword load per pixel; v_sad_u32 magnitudes; DPP ring for the
+//     horizontal neighbours; lane r captures row r, so a strip leaves as four 512-byte tile stores (details below).
+//   k_canny_nms2 (VQA_NMS_VARIANT=2, round 2's kernel): 4 pixels per lane, packed 16-bit Sobel, register-rolling.
+//   k_canny_nms  (VQA_NMS_VARIANT=1, round 1's kernel): 64x32 tile per workgroup through LDS, words built with __ballot.
+//   All: Sobel 3x3 on replicated borders, L1 magnitude = 0 outside the image (OpenCV's zero-bordered
 //   buffer), TG22 fixed-point sector test.
 // Stage 2 (k_canny_hyst_*): 8-connected hysteresis as an iterate-to-fixpoint on
 //   64x64-pixel tiles held ENTIRELY IN REGISTERS: lane r owns row r as a u64.
-//   One step = vertical neighbours by wave shuffles, 3-wide dilation by shifts,
-//   then a Kogge-Stone flood along the row (6 shift/and/or steps per direction),
-//   so a horizontal chain of any length is absorbed in ONE step.  Promotion is
-//   monotone (weak -> edge only), so the fixpoint is unique and independent of
-//   scheduling: the count is bit-exact with OpenCV's sequential stack walk.
+//   One step = vertical neighbours by whole-wave DPP shifts, 3x3 dilation, then a flood along the row done by the
+//   integer adder (carry propagation through runs; bit-reversed for the other direction), so a horizontal chain of
+//   any length is absorbed in ONE step.  Promotion is monotone (weak -> edge only), so the fixpoint is unique and
+//   independent of scheduling: the count is bit-exact with OpenCV's sequential stack walk.
 //   A tile re-enqueues a neighbour only when one of the neighbour's candidates touches a pixel it
-//   promoted (dedup flag + atomic append into per-frame lists).  Round 0 = every tile, rounds 1-4 = the
-//   lists on a wide grid, then one persistent workgroup per frame runs its frame's remaining rounds with
-//   an agent-scope release/acquire between rounds: the host never waits inside the fixpoint.
+//   promoted (dedup flag + one append-counter atomic per tile into one of 16 list segments per frame).  Round 0 =
+//   every tile, six rounds = the lists on a wide grid, then one persistent workgroup per frame runs its frame's
+//   remaining rounds with an agent-scope release/acquire between rounds: the host never waits inside the fixpoint.
+// Stage 3 (k_canny_count): np.sum(edges > 0) = the set bits of the final edge plane, one pass.
 //
-// Roofline: HBM, P + P/4 (+ P/4 per hysteresis pass over live tiles) bytes per frame.
+// Roofline: HBM, P + P/4 (+ P/4 per hysteresis pass over live tiles) bytes per frame; in practice stage 1 is bound by
+// the CU's scalar unit and the vector ALUs, stage 2 by latency.
 #include "vqa_dev.hpp"
 #include "vqa_kernels.hpp"
 #include "vqa_math.hpp"
@@ -751,26 +754,26 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
         }
         sr = to_row(cur);
     } else {
-    // One iteration = A.sub cheap sub-steps (each: rows above/below by lane shift, 3-wide dilation, promote the weak
-    // cells that touch an edge cell: a chain advances one row per sub-step, diagonals included) followed by ONE
-    // Kogge-Stone flood along the rows.  Promotion is monotone, so any schedule reaches the same fixpoint; a chain
-    // that runs down the tile costs ~45 instructions per row instead of a whole flood (~130) per row.
-    for (;;) {
-        steps++;
-        uint32_t any_c = 0;
-        for (int k = 0; k < A.sub; k++) {
-            row64 up = shfl_up_row(sr), dn = shfl_dn_row(sr);
-            if (lane == 0) up = esr;
-            if (lane == 63) dn = esr;
-            const row64 d = dil3(up, up_l, up_r) | dil3(sr, hl32, hr32) | dil3(dn, dn_l, dn_r);
-            // weak cells touching an edge cell that are not edges yet
-            const row64 cand = row64{wr.lo & d.lo & ~sr.lo, wr.hi & d.hi & ~sr.hi};
-            sr = sr | cand;
-            any_c |= cand.lo | cand.hi;
+        // One iteration = A.sub cheap sub-steps (each: rows above/below by lane shift, 3-wide dilation, promote the weak
+        // cells that touch an edge cell: a chain advances one row per sub-step, diagonals included) followed by ONE
+        // Kogge-Stone flood along the rows.  Promotion is monotone, so any schedule reaches the same fixpoint; a chain
+        // that runs down the tile costs ~45 instructions per row instead of a whole flood (~130) per row.
+        for (;;) {
+            steps++;
+            uint32_t any_c = 0;
+            for (int k = 0; k < A.sub; k++) {
+                row64 up = shfl_up_row(sr), dn = shfl_dn_row(sr);
+                if (lane == 0) up = esr;
+                if (lane == 63) dn = esr;
+                const row64 d = dil3(up, up_l, up_r) | dil3(sr, hl32, hr32) | dil3(dn, dn_l, dn_r);
+                // weak cells touching an edge cell that are not edges yet
+                const row64 cand = row64{wr.lo & d.lo & ~sr.lo, wr.hi & d.hi & ~sr.hi};
+                sr = sr | cand;
+                any_c |= cand.lo | cand.hi;
+            }
+            if (!__any(any_c != 0u)) break; // none anywhere in the tile during a whole iteration => fixpoint
+            sr = flood_row(sr, F);
         }
-        if (!__any(any_c != 0u)) break; // none anywhere in the tile during a whole iteration => fixpoint
-        sr = flood_row(sr, F);
-    }
     }
     const u64 s = to_u64(sr);
     const u64 promoted = s & ~s0;
