@@ -212,6 +212,25 @@ def test_canny_count_and_map(engine, name, low, high):
     assert int(rec[0]["edge_count"]) == cnt
 
 
+@pytest.mark.parametrize("w", [4, 5, 7, 8, 63, 64, 65, 255, 256, 257, 258, 259, 260, 261, 511, 512, 513, 514, 515, 516, 517, 770])
+def test_canny_strip_and_border_widths(engine, w):
+    """k_canny_nms3 works on 256-column strips with a one-column halo group and takes its interior (no realignment)
+    path only when a strip's dword windows stay inside the image (x0 + 259 <= w): every width around those seams, the
+    4-column minimum of the dword window (narrower frames take the byte-load kernel), two strips of rows, and
+    thresholds that are negative / swapped / zero."""
+    from rtvqa_amd import _native as N
+    h = 67
+    fr = _frames("natural", 2, h, w, seed=w)
+    fr[1, :, : max(w // 3, 1)] //= 3  # a hard vertical step so narrow frames carry edges too
+    for lo, hi in ((100, 200), (40, 20), (-5, 30), (0, 0)):
+        rec = engine.complexity(fr, mask=N.M_EDGE, canny=(lo, hi))
+        for i in range(2):
+            g = co.bgr2gray(fr[i])
+            cnt, strong, weak, emap = co.canny(g, min(lo, hi), max(lo, hi), want_map=True)
+            assert (int(rec[i]["edge_count"]), int(rec[i]["edge_strong"]), int(rec[i]["edge_weak"])) == (cnt, strong, weak), (w, lo, hi, i)
+            assert ((engine.debug_plane(2, i, h, w) != 0) == (emap != 0)).all(), (w, lo, hi, i)
+
+
 def test_canny_batch_of_mixed_frames(engine):
     from rtvqa_amd import _native as N
     fr = np.concatenate([_frames("natural", 3, 200, 328, seed=3), _frames("noise", 2, 200, 328, seed=4)])
