@@ -110,7 +110,8 @@ typedef struct vqa_frame_metrics {
     uint32_t edge_strong;        /* pixels above `high` that survive NMS                    */
     uint32_t edge_weak;          /* NMS survivors in (low, high]                            */
     uint32_t has_prev;           /* 1 if a previous frame was available                     */
-    uint32_t hyst_steps;         /* diagnostics only (scheduling-dependent): relaxation steps summed over tiles */
+    uint32_t hyst_steps;         /* diagnostics only (scheduling-dependent): relaxation steps summed over tile visits;
+                                    0 unless VQA_HYST_STATS=1 is set in the environment (it costs an atomic per visit) */
     uint32_t orb_keypoints;      /* len(ORB_create().detectAndCompute(gray64)[0])  (:385-389)  */
     uint32_t orb_response;       /* FAST score of that keypoint, 0 when there is none       */
     uint32_t hyst_overflow;      /* 1 if the Canny hysteresis hit its round bound before the fixpoint:

@@ -116,3 +116,27 @@ def test_pmc_traffic_goes_null_when_sources_changed(tmp_path, monkeypatch):
     (prof / "round9_c3_pmc.json").write_text(json.dumps(nohash))
     assert bench.pmc_traffic("c3", "k_ssim_gauss", 256, True)[0] is None
     assert bench.pmc_traffic("c3", "k_ssim_gauss", 256, False)[0] is None  # non-default modes have no PMC pass
+
+
+def test_verified_checker_accepts_the_oracle_and_rejects_a_wrong_record():
+    """bench.py's "verified": the expectation (oracle/check.py, computed before the GPU is touched) against result records.
+    A record filled from the oracle itself verifies; one wrong bin / count / float is reported."""
+    import numpy as np
+    from oracle import check
+    from rtvqa_amd.engine import FRAME_DTYPE, PLANE_DTYPE
+    assert bench.verify_frames(256) == [0, 1, 15, 16, 17, 128, 255] and bench.verify_frames(2) == [0, 1]
+    j, exp = bench._expect_item(("natural", 0, 48, 64, 4, 1, True, "sad", "gauss", False, "block8"))
+    assert j == 1
+    c = np.zeros(1, FRAME_DTYPE)[0]
+    c["dct_energy"], c["temporal_dct_l1"], c["sum_gray2"] = exp["dct_energy"], exp["temporal_dct_l1"], exp["sum_gray2"]
+    c["edge_count"], c["edge_strong"], c["edge_weak"] = exp["edge"]
+    c["sad_blocks"], c["sad_sum"] = exp["sad"]
+    c["mv_d2_hist"], c["hist_gray"], c["hist_bgr"], c["orb_keypoints"] = exp["mv_d2_hist"], exp["hist_gray"], exp["hist_bgr"], exp["orb"]
+    q = np.zeros(3, PLANE_DTYPE)
+    q["sse"], q["ssim"] = exp["sse"], exp["ssim_gauss"]
+    assert check.compare(exp, c, q, "gauss") == []
+    c["hist_bgr"][1][7] += 1
+    c["edge_count"] += 1
+    q["ssim"][2] *= 1.0 + 3e-4
+    bad = check.compare(exp, c, q, "gauss")
+    assert len(bad) == 3 and any("hist_bgr" in b for b in bad) and any("edge" in b for b in bad) and any("ssim_gauss[2]" in b for b in bad)
