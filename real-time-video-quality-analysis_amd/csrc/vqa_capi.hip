@@ -741,6 +741,14 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             for (round = 1; round <= WIDE; round++) {
                 const int in = round & 1, out = in ^ 1;
                 HIPCHK(c, hipMemsetAsync(counts + out * n * NS, 0, sizeof(uint32_t) * n * NS, st));
+                if (getenv("VQA_HYST_TRACE")) { // debugging aid: tiles queued for this round, summed over frames (synchronises)
+                    std::vector<uint32_t> hc((size_t)n * NS);
+                    (void)hipStreamSynchronize(st);
+                    (void)hipMemcpy(hc.data(), counts + in * n * NS, sizeof(uint32_t) * hc.size(), hipMemcpyDeviceToHost);
+                    unsigned long long tot = 0;
+                    for (uint32_t v : hc) tot += v;
+                    fprintf(stderr, "[hyst] round %d: %llu of %u tiles queued\n", round, tot, ntiles);
+                }
                 launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in * n * NS,
                                        queued[out], lists[out], counts + out * n * NS, res);
             }
