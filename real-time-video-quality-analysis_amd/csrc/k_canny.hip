@@ -832,9 +832,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // later rounds: the tiles some neighbour enqueued in the previous round
 __global__ __launch_bounds__(256) void k_canny_hyst_list(hyst_args A, const unsigned *__restrict__ in_list,
                                                          const unsigned *__restrict__ in_count,
-                                                         unsigned *__restrict__ in_queued)
+                                                         unsigned *__restrict__ in_queued,
+                                                         unsigned *__restrict__ zero_count)
 {
     const unsigned f = blockIdx.y, tpf = (unsigned)(A.tiles_y * A.ww);
+    // the counters the NEXT round appends to (nobody reads or writes them during this round: vqa_capi.hip)
+    if (blockIdx.x == 0 && threadIdx.x < HSEG) zero_count[f * HSEG + threadIdx.x] = 0;
     unsigned cnt[HSEG], n = 0;
 #pragma unroll
     for (int k = 0; k < HSEG; k++) { cnt[k] = in_count[f * HSEG + k]; n += cnt[k]; } // wave-uniform: scalar loads
@@ -975,7 +978,8 @@ void launch_canny_hyst_all(hipStream_t st, unsigned long long *strong, const uns
 
 void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *in_queued, const unsigned *in_list, const unsigned *in_count,
-                            unsigned *out_queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res)
+                            unsigned *out_queued, unsigned *out_list, unsigned *out_count, unsigned *zero_count,
+                            vqa_frame_metrics *res)
 {
     if (n <= 0) return;
     // workgroups per frame: ~64 tiles of the frame per 4-wave workgroup (1080p: 8, 2160p: 32)
@@ -984,7 +988,7 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
     gx = gx < 8 ? 8 : (gx > 32 ? 32 : gx);
     hipLaunchKernelGGL(k_canny_hyst_list, dim3(gx, n), dim3(256), 0, st,
                        make_hyst_args(strong, weak, h, w, out_queued, out_list, out_count, res), in_list, in_count,
-                       in_queued);
+                       in_queued, zero_count);
 }
 
 // rounds 2.. to convergence, one workgroup per frame, no host involvement.  lists/counts/queued: the two

@@ -709,14 +709,18 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         if (rc) return rc;
         rc = ensure(c, c->dirty1, sizeof(uint32_t) * ntiles * NS); // work list B
         if (rc) return rc;
-        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 2 * n * NS); // append counters of the two lists
+        rc = ensure(c, c->again_dev, sizeof(uint32_t) * 3 * n * NS); // append counters: three buffers, rotated per round (below)
         if (rc) return rc;
         unsigned long long *strong = (unsigned long long *)c->state.p, *weak = strong + words;
         unsigned *queued[2] = {(unsigned *)c->tile_flags.p, (unsigned *)c->tile_flags.p + ntiles};
         unsigned *lists[2] = {(unsigned *)c->dirty0.p, (unsigned *)c->dirty1.p};
         unsigned *counts = (unsigned *)c->again_dev.p;
         HIPCHK(c, hipMemsetAsync(queued[0], 0, sizeof(uint32_t) * ntiles * 2, st));
-        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * n * NS, st));
+        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 3 * n * NS, st));
+        // The append counters rotate over THREE buffers so that no memset sits between the rounds: round r consumes
+        // cnt(r), appends to cnt(r + 1) and zeroes cnt(r + 2) - the buffer round r - 1 consumed (stream order: done)
+        // and round r + 1 will append to.  Lists and dedup flags stay double-buffered (index r & 1).
+        auto cnt = [&](int r) { return counts + (size_t)(r % 3) * n * NS; };
         int lo = P.canny_low, hi = P.canny_high;
         if (lo > hi) { int t = lo; lo = hi; hi = t; }
         {
@@ -728,7 +732,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         int round = 0;
         {
             prof_scope ps_(c, VQA_K_CANNY_HYST);
-            launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], counts + n * NS, res);
+            launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], cnt(1), res);
         }
         {
             // rounds 1..WIDE (still many tiles): wide grid over the per-frame lists; then the tail kernel
@@ -740,20 +744,23 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             if (const char *e = getenv("VQA_HYST_WIDE")) WIDE = atoi(e) > 0 ? atoi(e) : WIDE; // tuning knob
             for (round = 1; round <= WIDE; round++) {
                 const int in = round & 1, out = in ^ 1;
-                HIPCHK(c, hipMemsetAsync(counts + out * n * NS, 0, sizeof(uint32_t) * n * NS, st));
                 if (getenv("VQA_HYST_TRACE")) { // debugging aid: tiles queued for this round, summed over frames (synchronises)
                     std::vector<uint32_t> hc((size_t)n * NS);
                     (void)hipStreamSynchronize(st);
-                    (void)hipMemcpy(hc.data(), counts + in * n * NS, sizeof(uint32_t) * hc.size(), hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(hc.data(), cnt(round), sizeof(uint32_t) * hc.size(), hipMemcpyDeviceToHost);
                     unsigned long long tot = 0;
                     for (uint32_t v : hc) tot += v;
                     fprintf(stderr, "[hyst] round %d: %llu of %u tiles queued\n", round, tot, ntiles);
                 }
-                launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], counts + in * n * NS,
-                                       queued[out], lists[out], counts + out * n * NS, res);
+                launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], cnt(round), queued[out], lists[out],
+                                       cnt(round + 1), cnt(round + 2), res);
             }
-            launch_canny_hyst_tail(st, strong, weak, n, ph, pw, lists[0], counts, queued[0], lists[1], counts + n * NS,
-                                   queued[1], round & 1, res);
+            // the tail alternates between the counter the last wide round appended to and the one it zeroed
+            unsigned *tc[2];
+            tc[round & 1] = cnt(round);
+            tc[(round & 1) ^ 1] = cnt(round + 1);
+            launch_canny_hyst_tail(st, strong, weak, n, ph, pw, lists[0], tc[0], queued[0], lists[1], tc[1], queued[1],
+                                   round & 1, res);
         }
         launch_canny_finish(st, strong, n, ph, pw, res);
         c->last_has_state = true;

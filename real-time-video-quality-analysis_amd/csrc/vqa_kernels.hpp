@@ -47,7 +47,8 @@ void launch_canny_hyst_all(hipStream_t st, unsigned long long *strong, const uns
                            int w, unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res);
 void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *in_queued, const unsigned *in_list, const unsigned *in_count,
-                            unsigned *out_queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res);
+                            unsigned *out_queued, unsigned *out_list, unsigned *out_count, unsigned *zero_count,
+                            vqa_frame_metrics *res);
 void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *list0, unsigned *cnt0, unsigned *q0, unsigned *list1, unsigned *cnt1,
                             unsigned *q1, int first_in, vqa_frame_metrics *res);
