@@ -6,12 +6,17 @@
          --master-port P bench.py --gpus N --steps K --warmup W   (N > 1, one rank per GPU)
 
 A "step" is one pass of the selected workload over one device-resident batch of
-frames.  Rank 0 prints ONE JSON line (contract in the task statement) with three
-extra objects: "roofline" (dominant kernel, algorithmic bytes / HIP-event time),
-"end_to_end" (the same workload fed from pinned host memory over PCIe, measured
-after the timed region; never `value`) and, at N = 1, "cpu_baseline" (the oracle
-port under a process pool that reproduces the reference's process_in_batches,
-timed on this box's host cores).
+frames.  Rank 0 prints ONE JSON line (contract in the task statement) with four
+extra objects: "roofline" (dominant kernel: algorithmic bytes / HIP-event time
+against the HBM peak, or - for a kernel far below that roof that does counted fp32
+work - flops against the fp32 vector peak, "bound": "valu_fp32"), "end_to_end"
+(the same workload fed from pinned host memory over PCIe, measured after the
+timed region; never `value`), at N = 1 "cpu_baseline" (the oracle port under a
+process pool that reproduces the reference's process_in_batches, timed on this
+box's host cores) and "verified": the result records of the LAST TIMED step at a
+few batch positions are compared with what the oracle expects for those frames
+(expectations computed before the process touches the GPU); a mismatch is fatal
+on every rank (exit code 4) and no line is printed.
 
 Workloads (BASELINE.json configs):
   c3  1920x1080 full complexity suite + PSNR/SSIM          [default: the config BASELINE.json's metric is quoted on]
