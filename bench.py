@@ -159,8 +159,8 @@ def cpu_baseline(h, w, full, sample, motion="sad", verify_items=()):
     co.build()
     cores = visible_cores()
     workers, override = cpu_workers(cores)
-    if sample <= 0:  # bounded sample: every worker gets a few items, ~10-30 s of CPU work at 1080p
-        sample = max(32, 3 * workers)
+    if sample <= 0:  # bounded sample: every worker gets a few items, ~10-30 s of CPU work (scaled with the frame area)
+        sample = max(8, int(max(32, 3 * workers) * (1920.0 * 1080.0) / (h * w)))
     ref = synth.s_natural(sample, h, w, seed=1234, stream_id=0, t0=0)
     dist = synth.distort(ref, t0=0)
     items = [(ref[i], dist[i], dist[i - 1] if i else dist[0], full, motion) for i in range(sample)]
