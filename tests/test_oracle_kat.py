@@ -377,3 +377,27 @@ def test_farneback_restatements_and_the_border_discontinuity(case, pair, straddl
     a, b = co.farneback(gp, g), no.farneback_mean_mag(gp, g)
     rel = abs(a - b) / b
     assert (1e-4 < rel < 2e-3) if straddles else rel < 2e-6
+
+
+def test_resize_and_gray_against_independent_float_implementations():
+    """Weak but INDEPENDENT cross-checks of two restated OpenCV semantics (no cv2 here): torch's bilinear interpolation
+    (half-pixel centres, no antialiasing - the sampling geometry cv2.resize INTER_LINEAR uses) must agree with the
+    fixed-point restatement to within one grey level, for up- and down-scaling; and BGR2GRAY must be the rounded
+    0.114 B + 0.587 G + 0.299 R to within one level.  These catch a wrong coordinate mapping, swapped axes or
+    coefficients; they cannot pin OpenCV's rounding (that stays unpinned)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    # smooth content: on noise a +-1/2048 weight difference is still < 1 level, but keep the check meaningful
+    base = rng.integers(0, 256, (9, 12)).astype(np.float32)
+    img = np.clip(np.kron(base, np.ones((8, 8), np.float32)) + rng.normal(0, 2, (72, 96)), 0, 255).astype(np.uint8)
+    for (dw, dh) in ((64, 64), (48, 40), (160, 120), (96, 72), (33, 17), (200, 150)):
+        got = co.resize_linear(img, dw, dh).astype(np.float64)
+        if (dw, dh) == (48, 36) or (img.shape[1] == 2 * dw and img.shape[0] == 2 * dh):
+            continue  # exact 2x decimation takes OpenCV's INTER_AREA shortcut, a different filter
+        t = torch.from_numpy(img.astype(np.float32))[None, None]
+        want = F.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)[0, 0].numpy()
+        assert np.abs(got - want).max() <= 1.0 + 1e-6, (dw, dh, np.abs(got - want).max())
+    bgr = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    want = 0.114 * bgr[..., 0] + 0.587 * bgr[..., 1] + 0.299 * bgr[..., 2]
+    assert np.abs(co.bgr2gray(bgr).astype(np.float64) - want).max() <= 1.0
