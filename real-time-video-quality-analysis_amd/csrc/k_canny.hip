@@ -310,16 +310,17 @@ __global__ __launch_bounds__(64) void k_canny_nms2(const uint8_t *__restrict__ g
 // are the 64 columns of tile k and a vector compare of group k IS that tile row's bit-plane word (one
 // v_cmp writing an SGPR pair): every NMS decision is taken on 64-pixel masks by the scalar unit, there is no
 // per-pixel branch, no nibble assembly and no unpacking.
-//   * gray: 3 buffer_load_ubyte per pixel (x-1, x, x+1; clamped column offsets are loop-invariant VGPRs, the row
-//     offset is the instruction's scalar offset), so addressing costs no vector instruction;
-//   * gradient, 8 vector instructions per pixel: h1 = p[x+1] - p[x-1], h2 = p[x-1] + 2 p[x] + p[x+1]; rows are
-//     combined through running sums (gx + 1024 = s[R-1] + s[R], s[R] = h1[R-1] + h1[R] + 512) and the L1
-//     magnitude is two v_sad_u32: ax = |gx + 1024 - 1024|, m = |h2[R] - h2[R-2]| + ax (gy is never formed);
+//   * gray: ONE unaligned buffer_load_dword per pixel (the bytes x-1 .. x+2; the lane offset is a loop-invariant
+//     VGPR, the row offset the instruction's scalar offset, so addressing costs no vector instruction), requested one
+//     row ahead; a wave that touches the image border realigns the replicated-border bytes with one v_perm_b32;
+//   * gradient, 7 vector instructions per pixel: h1 = p[x+1] - p[x-1] (v_sub_u32_sdwa), h2 = p[x-1] + 2 p[x] + p[x+1]
+//     (v_dot4_u32_u8); rows are combined through running sums (gx + 1024 = s[R-1] + s[R], s[R] = h1[R-1] + h1[R] + 512)
+//     and the L1 magnitude is two v_sad_u32: ax = |gx + 1024 - 1024|, m = |h2[R] - h2[R-2]| + ax (gy is never formed);
 //   * horizontal neighbours: the five column groups (4 tiles + a halo group whose lane 63 / lane 0 are the
 //     columns left / right of the wave's span) form a ring; wave_ror:1 / wave_rol:1 DPP moves plus one select
 //     for the seam lane give every row's m[x-1] and m[x+1] once, when the row is new;
-//   * sector test on integers (TG22 fixed point, OpenCV's own): r = (ay << 15) - 13573 ax, horizontal iff r < 0,
-//     vertical iff r - (ax << 16) > 0, else diagonal with the sign test (gx ^ gy) < 0 = two compares;
+//   * sector test on integers (TG22 fixed point, OpenCV's own), as two unsigned compares of m << 15 against
+//     46341 |gx| and 111877 |gx| (|gy| = m - |gx|); the diagonal's sign test (gx ^ gy) < 0 is two compares;
 //   * all compares between two consecutive rows are made once, when the lower row is new, and serve both rows
 //     (as "below" of the upper one, as "above" of the lower one): only TWO rows of magnitudes live in registers,
 //     the upper row's partial decisions wait in scalar registers as masks;
