@@ -330,6 +330,10 @@ def main():
                     help="block8 (default, north_star's 8x8 DCT) or full (the reference's full-frame cv2.dct, on fp32 MFMA)")
     ap.add_argument("--motion", default="sad", choices=["sad", "farneback"],
                     help="motion metric of the full suite: sad (north_star's block-SAD, default) or farneback (the reference's own)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="VQA_OVERLAP=1: block-SAD and the Canny chain fork onto side streams inside the complexity submit "
+                         "(+3 %% fps on c3; the event times of the overlapped kernels then include sharing the GPU, so their "
+                         "sum exceeds the step time). Off by default to keep the per-kernel accounting clean")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
                     help="skip the post-timing check of the last timed step's records against the oracle")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -346,6 +350,8 @@ def main():
     if args.stub_engine and args.backend != "gloo":
         raise SystemExit("--stub-engine is a CPU rehearsal: use --backend gloo")
 
+    if args.overlap:
+        os.environ["VQA_OVERLAP"] = "1"  # read once by the library, at the first complexity submit
     wl = WORKLOADS[args.workload]
     h, w, full = wl["h"], wl["w"], wl["full"]
     B = args.batch or wl["batch"]
@@ -534,7 +540,8 @@ def main():
                   "collective": ("%s scalar all-reduce" % ("rccl" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
                   "rccl_ranks": rccl_ranks, "devices": devices, "rehearsal_single_device": bool(rehearsal and world > 1),
                   "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode,
-                  "motion": args.motion, "parallelism": "1 stream/GPU x%d" % world}
+                  "motion": args.motion, "parallelism": "1 stream/GPU x%d" % world,
+                  "overlap": bool(args.overlap or os.environ.get("VQA_OVERLAP", "0") not in ("", "0"))}
         if stub:
             line.update({"data": "STUB: no kernels ran (rank-logic rehearsal, --stub-engine)", "stub": True, "config": config,
                          "roofline": None, "kernels": {}})

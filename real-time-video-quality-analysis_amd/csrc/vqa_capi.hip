@@ -37,6 +37,8 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 struct vqa_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t side[2] = {nullptr, nullptr};   // VQA_OVERLAP=1: block-SAD and the Canny chain on their own streams
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::string last_err;
 
     // device scratch (grow-only)
@@ -78,16 +80,17 @@ struct prof_scope {
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
-    prof_scope(vqa_ctx *c_, int id_) : c(c_), id(id_)
+    hipStream_t s;
+    prof_scope(vqa_ctx *c_, int id_, hipStream_t s_ = nullptr) : c(c_), id(id_), s(s_ ? s_ : c_->stream)
     {
         if (!c->prof_on) return;
         a = get(c); b = get(c);
-        if (a && b) (void)hipEventRecord(a, c->stream);
+        if (a && b) (void)hipEventRecord(a, s);
     }
     ~prof_scope()
     {
         if (!a || !b) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, s);
         c->ev_open.emplace_back(id, a, b);
     }
 };
@@ -469,6 +472,11 @@ int vqa_destroy(vqa_ctx *c)
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->qres_host) (void)hipHostFree(c->qres_host);
+    for (int i = 0; i < 2; i++) {
+        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return VQA_OK;
@@ -683,11 +691,27 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         }
     }
 
+    // ---- VQA_OVERLAP=1 (experiment): block-SAD, the Canny chain and DCT/ORB only share the gray planes as input, so
+    // they may run side by side: SAD and Canny fork onto their own streams here and join before the results are copied
+    static int overlap = -1;
+    if (overlap < 0) { const char *e = getenv("VQA_OVERLAP"); overlap = (e && atoi(e) > 0) ? 1 : 0; }
+    hipStream_t st_sad = st, st_canny = st;
+    if (overlap) {
+        for (int i = 0; i < 2; i++) {
+            if (!c->side[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+            if (!c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        }
+        if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        st_sad = c->side[0]; st_canny = c->side[1];
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(st_sad, c->ev_fork, 0));
+        HIPCHK(c, hipStreamWaitEvent(st_canny, c->ev_fork, 0));
+    }
     // ---- motion on the full-resolution gray planes (the reference never resizes for it, :327-328):
     // block-SAD (north_star) or the reference's own Farneback flow
     if (want_m && P.motion_mode == VQA_MOTION_SAD) {
-        prof_scope ps_(c, VQA_K_SAD);
-        launch_block_sad(st, gfull, gp, full_stride, n, h, w, P.sad_range, has_prev0, res);
+        prof_scope ps_(c, VQA_K_SAD, st_sad);
+        launch_block_sad(st_sad, gfull, gp, full_stride, n, h, w, P.sad_range, has_prev0, res);
     } else if (want_m) {
         prof_scope ps_(c, VQA_K_FARNEBACK);
         rc = run_farneback(c, st, gfull, gp, full_stride, n, h, w, has_prev0, res);
@@ -715,8 +739,8 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         unsigned *queued[2] = {(unsigned *)c->tile_flags.p, (unsigned *)c->tile_flags.p + ntiles};
         unsigned *lists[2] = {(unsigned *)c->dirty0.p, (unsigned *)c->dirty1.p};
         unsigned *counts = (unsigned *)c->again_dev.p;
-        HIPCHK(c, hipMemsetAsync(queued[0], 0, sizeof(uint32_t) * ntiles * 2, st));
-        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 3 * n * NS, st));
+        HIPCHK(c, hipMemsetAsync(queued[0], 0, sizeof(uint32_t) * ntiles * 2, st_canny));
+        HIPCHK(c, hipMemsetAsync(counts, 0, sizeof(uint32_t) * 3 * n * NS, st_canny));
         // The append counters rotate over THREE buffers so that no memset sits between the rounds: round r consumes
         // cnt(r), appends to cnt(r + 1) and zeroes cnt(r + 2) - the buffer round r - 1 consumed (stream order: done)
         // and round r + 1 will append to.  Lists and dedup flags stay double-buffered (index r & 1).
@@ -724,20 +748,20 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         int lo = P.canny_low, hi = P.canny_high;
         if (lo > hi) { int t = lo; lo = hi; hi = t; }
         {
-            prof_scope ps_(c, VQA_K_CANNY_NMS);
-            launch_canny_nms(st, pB, pp, plane_stride, n, ph, pw, lo, hi, strong, weak, res);
+            prof_scope ps_(c, VQA_K_CANNY_NMS, st_canny);
+            launch_canny_nms(st_canny, pB, pp, plane_stride, n, ph, pw, lo, hi, strong, weak, res);
         }
         // hysteresis to the fixpoint, entirely enqueued (no host readback).  Round 0 relaxes every tile;
         // round r > 0 relaxes the tiles that round r-1 enqueued into lists[r & 1].
         int round = 0;
         {
-            prof_scope ps_(c, VQA_K_CANNY_HYST);
-            launch_canny_hyst_all(st, strong, weak, n, ph, pw, queued[1], lists[1], cnt(1), res);
+            prof_scope ps_(c, VQA_K_CANNY_HYST, st_canny);
+            launch_canny_hyst_all(st_canny, strong, weak, n, ph, pw, queued[1], lists[1], cnt(1), res);
         }
         {
             // rounds 1..WIDE (still many tiles): wide grid over the per-frame lists; then the tail kernel
             // finishes every frame on its own workgroup with no host round-trip.
-            prof_scope ps_(c, VQA_K_CANNY_HYST);
+            prof_scope ps_(c, VQA_K_CANNY_HYST, st_canny);
             // (a frame's tail runs on ONE workgroup: big frames in small batches get more wide rounds first)
             const canny_geom cg = canny_tiles(ph, pw);
             int WIDE = (cg.tiles_x * cg.tiles_y > 1024 && n < 256) ? 8 : 6; // (measured: 1080p x 256: 4 -> 0.40 ms, 6 -> 0.38 ms of hysteresis)
@@ -746,23 +770,23 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
                 const int in = round & 1, out = in ^ 1;
                 if (getenv("VQA_HYST_TRACE")) { // debugging aid: tiles queued for this round, summed over frames (synchronises)
                     std::vector<uint32_t> hc((size_t)n * NS);
-                    (void)hipStreamSynchronize(st);
+                    (void)hipStreamSynchronize(st_canny);
                     (void)hipMemcpy(hc.data(), cnt(round), sizeof(uint32_t) * hc.size(), hipMemcpyDeviceToHost);
                     unsigned long long tot = 0;
                     for (uint32_t v : hc) tot += v;
                     fprintf(stderr, "[hyst] round %d: %llu of %u tiles queued\n", round, tot, ntiles);
                 }
-                launch_canny_hyst_list(st, strong, weak, n, ph, pw, queued[in], lists[in], cnt(round), queued[out], lists[out],
+                launch_canny_hyst_list(st_canny, strong, weak, n, ph, pw, queued[in], lists[in], cnt(round), queued[out], lists[out],
                                        cnt(round + 1), cnt(round + 2), res);
             }
             // the tail alternates between the counter the last wide round appended to and the one it zeroed
             unsigned *tc[2];
             tc[round & 1] = cnt(round);
             tc[(round & 1) ^ 1] = cnt(round + 1);
-            launch_canny_hyst_tail(st, strong, weak, n, ph, pw, lists[0], tc[0], queued[0], lists[1], tc[1], queued[1],
+            launch_canny_hyst_tail(st_canny, strong, weak, n, ph, pw, lists[0], tc[0], queued[0], lists[1], tc[1], queued[1],
                                    round & 1, res);
         }
-        launch_canny_finish(st, strong, n, ph, pw, res);
+        launch_canny_finish(st_canny, strong, n, ph, pw, res);
         c->last_has_state = true;
     }
 
@@ -773,6 +797,12 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         if (rc) return rc;
         prof_scope ps_(c, VQA_K_ORB);
         launch_orb64(st, dframes, n, h, w, frame_stride, row_stride, T64.xofs, T64.xa, T64.yofs, T64.yb, T64.mode, res);
+    }
+    if (overlap) {
+        HIPCHK(c, hipEventRecord(c->ev_join[0], st_sad));
+        HIPCHK(c, hipEventRecord(c->ev_join[1], st_canny));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[0], 0));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[1], 0));
     }
     c->last_n = n; c->last_has_full = need_full; c->last_has_planes = need_planes; // (debug planes show the last slice)
     return VQA_OK;

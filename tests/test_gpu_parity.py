@@ -739,7 +739,7 @@ _VARIANT_CODE = (
 
 @pytest.mark.parametrize("knob", ["VQA_DCT_VARIANT=4", "VQA_DCT_VARIANT=3", "VQA_DCT_VARIANT=1", "VQA_DCT_LOAD_EARLY=1", "VQA_DCT_FCH=3",
                                   "VQA_SSIM_VARIANT=1", "VQA_SSIM_VARIANT=4", "VQA_NMS_VARIANT=1", "VQA_NMS_VARIANT=2", "VQA_HYST_SUB=1",
-                                  "VQA_HYST_SUB=5", "VQA_HYST_WIDE=1", "VQA_HYST_STATS=1"])
+                                  "VQA_HYST_SUB=5", "VQA_HYST_WIDE=1", "VQA_HYST_STATS=1", "VQA_OVERLAP=1"])
 def test_ab_knob_variants_keep_parity(knob):
     """Every A/B kernel variant kept in the library for re-measurement still matches the oracle
     (the knobs are read once per process => one subprocess per setting)."""
