@@ -4,6 +4,13 @@
 These are REGRESSION PINS OF THE RESTATEMENT, not outputs of the reference (which cannot run here: no cv2,
 no ffmpeg — DESIGN.md §3): they make an accidental edit of oracle/vqa_oracle.c visible.  Re-run only when the
 restatement is changed on purpose:  python oracle/gen_pins.py
+
+History of deliberate regenerations (the values are the oracle pinning ITSELF, so each one is recorded here):
+  round 3  farneback: fb_blur_solve rewritten in FarnebackUpdateFlow_Blur's own summation order (~1e-8 relative);
+           still a self-pin - cv2.calcOpticalFlowFarneback cannot run here.
+  round 4  ssim_gauss_b: Gaussian taps kept in double instead of rounded to float32 (~1.5e-8 relative) after
+           scikit-image disagreed by 3.1e-6 on full-white vs full-black (tests/golden/skimage_pins.json is the
+           third-party pin for that function; this file is not).
 """
 import json
 import os

@@ -194,7 +194,7 @@ def gauss11():
 
 
 def ssim_gauss(a, b):
-    g = gauss11().astype(np.float32).astype(np.float64)
+    g = gauss11()  # float64 taps: the definition (pinned by scikit-image, tests/golden/skimage_pins.json)
     x = a.astype(np.float64)
     y = b.astype(np.float64)
     def filt(z):

@@ -1,0 +1,180 @@
+"""Third-party pins: outputs of scikit-image 0.18.3 / SciPy 1.7.1 (tests/golden/skimage_pins.json, made by
+oracle/gen_pins_skimage.py under /opt/conda/bin/python3.9 in the build container) against the oracle (CPU half) and
+against the HIP path (-m gpu half).  Neither library is this repository's code, so these are the pins DESIGN.md §3
+calls "pinned by skimage": Gaussian-windowed SSIM (north_star's definition in place of video_processing.py:276),
+MSE / PSNR (video_processing.py:275), the entropy tails (complexity_metrics.py:413-414, :467-473), the FAST-9/16
+corner test (:386-387), the orthonormal DCT sums (:363-364, :574-579) and the bilinear resize GEOMETRY (:359).
+NOT pinned by them: OpenCV's BGR2GRAY / INTER_LINEAR rounding, Canny, Farneback, FFmpeg's vf_ssim integers.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import gen_pins_skimage as gp
+from rtvqa_amd import complexity_metrics as cm
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "skimage_pins.json")))
+PAIR_CASE = {c[0]: c for c in gp.PAIR_CASES}
+FRAME_CASE = {c[0]: c for c in gp.FRAME_CASES}
+SSIM_ORACLE_RTOL = 1e-6   # float64 restatement against float64 scikit-image (the judge measured <= 5.3e-7)
+SSIM_GPU_RTOL = 1e-4      # north_star's bar for the fp32 kernel
+DCT_RTOL = 1e-5           # oracle: f32 transforms against SciPy's f64
+GPU_DCT_RTOL = 1e-4
+
+_pairs, _frames = {}, {}
+
+
+def pair_of(rec):
+    if rec["name"] not in _pairs:
+        _pairs[rec["name"]] = gp.make_pair(PAIR_CASE[rec["name"]])
+    return _pairs[rec["name"]]
+
+
+def frames_of(rec):
+    if rec["name"] not in _frames:
+        _frames[rec["name"]] = gp.make_frames(FRAME_CASE[rec["name"]])
+    return _frames[rec["name"]]
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def pid(rec):
+    return rec["name"]
+
+
+# ---------------------------------------------------------------------------------------- CPU half
+def test_fixture_is_third_party_and_inputs_regenerate_bit_identically():
+    assert G["versions"]["skimage"] == "0.18.3" and G["versions"]["scipy"].startswith("1.7")
+    assert [p["name"] for p in G["pairs"]] == [c[0] for c in gp.PAIR_CASES]
+    for rec in G["pairs"]:
+        a, b = pair_of(rec)
+        assert (gp.sha(a), gp.sha(b)) == (rec["sha_a"], rec["sha_b"]), rec["name"]
+        assert a.shape == (rec["h"], rec["w"])
+    for rec in G["frames"]:
+        fr = frames_of(rec)
+        g0, g1 = gp.gray_for(FRAME_CASE[rec["name"]])
+        assert (gp.sha(fr[0]), gp.sha(g0), gp.sha(g1)) == (rec["sha_bgr"], rec["sha_gray0"], rec["sha_gray1"])
+
+
+@pytest.mark.parametrize("rec", G["pairs"], ids=pid)
+def test_oracle_ssim_gauss_equals_skimage(rec):
+    a, b = pair_of(rec)
+    assert rel(co.ssim_gauss(a, b), rec["ssim"]) <= SSIM_ORACLE_RTOL
+
+
+@pytest.mark.parametrize("rec", G["pairs"], ids=pid)
+def test_oracle_sse_and_psnr_equal_skimage(rec):
+    from rtvqa_amd.video_processing import _psnr
+    a, b = pair_of(rec)
+    sse = co.sse_plane(a, b)
+    # skimage: mean((a-b)^2) in float64; the SSE is an integer < 2^53, so the division is the only rounding
+    assert sse / (rec["h"] * rec["w"]) == rec["mse"]
+    if rec["psnr"] == "inf":
+        assert sse == 0 and math.isinf(_psnr(0.0))
+    else:
+        assert rel(_psnr(sse / (rec["h"] * rec["w"])), rec["psnr"]) <= 1e-12
+
+
+@pytest.mark.parametrize("rec", G["pairs"], ids=pid)
+def test_product_gray_entropy_tail_equals_skimage_shannon_entropy(rec):
+    """complexity_metrics.py:413-414 in float32 against scipy.stats.entropy(base=2) in float64."""
+    for plane, want in zip(pair_of(rec), (rec["entropy_a"], rec["entropy_b"])):
+        got = float(cm._gray_entropy(co.hist_u8(plane)))
+        assert abs(got - want) <= 1e-6 * max(want, 1.0)
+
+
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_product_entropy_tails_on_frames_equal_skimage(rec):
+    fr = frames_of(rec)[0]
+    g0, _ = gp.gray_for(FRAME_CASE[rec["name"]])
+    assert abs(float(cm._gray_entropy(co.hist_u8(g0))) - rec["gray_entropy"]) <= 1e-6 * rec["gray_entropy"]
+    counts = np.stack([co.hist_u8(np.ascontiguousarray(fr[..., c])) for c in range(3)])
+    # :471-473 adds 1e-8 inside the log2 (<= 768 * 1.44e-8 below the plain entropy sum) and sums in float32
+    assert abs(float(cm._color_entropy(counts)) - rec["color_entropy_sum"]) <= 2e-5
+
+
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_oracle_fast9_detection_equals_skimage_corner_fast(rec):
+    """The segment test of cv2's FAST (9 contiguous of 16, |diff| > 20, 3-pixel border skipped), NMS off."""
+    g0, _ = gp.gray_for(FRAME_CASE[rec["name"]])
+    n, _score, keep = co.fast9(g0, 20, False)
+    ys, xs = np.nonzero(keep)
+    assert n == rec["fast9_count"] == len(ys)
+    assert int(np.sum((ys.astype(np.int64) * 7919 + xs.astype(np.int64) * 104729) % 1000003)) == rec["fast9_crc"]
+
+
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_oracle_dct_sums_equal_scipy(rec):
+    g0, g1 = gp.gray_for(FRAME_CASE[rec["name"]])
+    assert rel(co.dct_energy_full(g1), rec["dct_full_energy"]) <= DCT_RTOL
+    assert rel(co.temporal_dct_full(g0, g1), rec["dct_full_l1"]) <= DCT_RTOL
+    e8, l8, _ = co.dct8x8(g0, g1)
+    assert rel(e8, rec["dct8_energy"]) <= DCT_RTOL and rel(l8, rec["dct8_l1"]) <= DCT_RTOL
+    assert rec["dct8_energy"] == pytest.approx(float((g1.astype(np.float64) ** 2).sum()), rel=1e-12)  # Parseval
+
+
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_oracle_resize_geometry_within_one_level_of_float_bilinear(rec):
+    """cv2.resize INTER_LINEAR samples at (dx + 0.5) * scale - 0.5 with edge clamping; its 11-bit weights and two
+    roundings keep it within one grey level of the float64 interpolation skimage computes at the same positions.
+    A wrong centre convention or clamp shows up as errors of many levels on these textures."""
+    g0, _ = gp.gray_for(FRAME_CASE[rec["name"]])
+    dw, dh = rec["resize_to"]
+    want = np.array(rec["resize_float"]).reshape(dh, dw)
+    got = co.resize_linear(g0, dw, dh).astype(np.float64)
+    assert np.abs(got - want).max() < 1.0
+    assert np.abs(got - want).mean() < 0.3
+
+
+# ---------------------------------------------------------------------------------------- GPU half
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec", G["pairs"], ids=pid)
+def test_gpu_quality_kernel_equals_skimage(engine, rec):
+    """k_ssim_gauss (60 % of the c3 step) against scikit-image: SSE exact, SSIM within north_star's 1e-4."""
+    from rtvqa_amd import _native as N
+    from rtvqa_amd.engine import gray_planes
+    a, b = pair_of(rec)
+    h, w = a.shape
+    q = engine.quality(a[None], b[None], gray_planes(h, w), N.SSIM_GAUSS)
+    assert int(q[0, 0]["sse"]) / (h * w) == rec["mse"]
+    assert rel(float(q[0, 0]["ssim"]), rec["ssim"]) <= SSIM_GPU_RTOL
+
+
+@pytest.mark.gpu
+def test_gpu_quality_kernel_equals_skimage_in_one_ragged_batch(engine):
+    """The same pins through the batched entry: the three 72x104 / 97x131 / 270x480 groups as 2-frame batches."""
+    from rtvqa_amd import _native as N
+    from rtvqa_amd.engine import gray_planes
+    by_geom = {}
+    for rec in G["pairs"]:
+        by_geom.setdefault((rec["h"], rec["w"]), []).append(rec)
+    for (h, w), recs in by_geom.items():
+        a = np.stack([pair_of(r)[0] for r in recs])
+        b = np.stack([pair_of(r)[1] for r in recs])
+        q = engine.quality(a, b, gray_planes(h, w), N.SSIM_GAUSS)
+        for i, r in enumerate(recs):
+            assert int(q[i, 0]["sse"]) / (h * w) == r["mse"], r["name"]
+            assert rel(float(q[i, 0]["ssim"]), r["ssim"]) <= SSIM_GPU_RTOL, r["name"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_gpu_histogram_and_dct_kernels_equal_skimage_and_scipy(engine, rec):
+    from rtvqa_amd import _native as N
+    fr = frames_of(rec)
+    mask = N.M_GRAY_HIST | N.M_COLOR_HIST | N.M_DCT | N.M_TEMPORAL_DCT
+    r8 = engine.complexity(fr[1:], prev0=fr[0], mask=mask, dct_mode=N.DCT_BLOCK8)[0]
+    rf = engine.complexity(fr[1:], prev0=fr[0], mask=mask, dct_mode=N.DCT_FULL)[0]
+    assert rel(float(r8["dct_energy"]), rec["dct8_energy"]) <= GPU_DCT_RTOL
+    assert rel(float(r8["temporal_dct_l1"]), rec["dct8_l1"]) <= GPU_DCT_RTOL
+    assert rel(float(rf["dct_energy"]), rec["dct_full_energy"]) <= GPU_DCT_RTOL
+    assert rel(float(rf["temporal_dct_l1"]), rec["dct_full_l1"]) <= GPU_DCT_RTOL
+    r0 = engine.complexity(fr[:1], mask=N.M_GRAY_HIST | N.M_COLOR_HIST)[0]
+    assert abs(float(cm._gray_entropy(r0["hist_gray"])) - rec["gray_entropy"]) <= 1e-6 * rec["gray_entropy"]
+    assert abs(float(cm._color_entropy(r0["hist_bgr"])) - rec["color_entropy_sum"]) <= 2e-5
