@@ -22,6 +22,16 @@
  *
  * There is NO CPU fallback: vqa_create fails with VQA_ERR_NO_DEVICE when no
  * gfx950 device is visible.
+ *
+ * Environment.  The shipped library reads exactly ONE environment variable, once per
+ * vqa_create: VQA_OVERLAP (0 / 1) = the initial value of VQA_OPT_OVERLAP below (a
+ * scheduling choice; results are identical either way).  No environment variable
+ * selects a kernel or changes an arithmetic path.  (The Python binding additionally
+ * honours VQA_LIB_PATH to load another build of this ABI, and VQA_DEVICE.)  A separate
+ * LAB build (`make -C csrc lab` -> lab/libvqa_hip_lab.so, vqa_build_flavour() != 0)
+ * keeps superseded kernels and test seams behind VQA_*_VARIANT / VQA_COMM_FAKE_RCCL /
+ * VQA_HYST_MAX_ROUNDS / VQA_FAIL_ENSURE_AT; it is for re-measurement and fault
+ * injection only and is never loaded by default.
  */
 #ifndef VQA_H
 #define VQA_H
@@ -39,7 +49,7 @@ extern "C" {
 #define VQA_API
 #endif
 
-#define VQA_ABI_VERSION 4
+#define VQA_ABI_VERSION 5
 
 typedef enum vqa_status {
     VQA_OK = 0,
@@ -111,7 +121,7 @@ typedef struct vqa_frame_metrics {
     uint32_t edge_weak;          /* NMS survivors in (low, high]                            */
     uint32_t has_prev;           /* 1 if a previous frame was available                     */
     uint32_t hyst_steps;         /* diagnostics only (scheduling-dependent): relaxation steps summed over tile visits;
-                                    0 unless VQA_HYST_STATS=1 is set in the environment (it costs an atomic per visit) */
+                                    0 unless VQA_OPT_HYST_STATS is set on the ctx (it costs an atomic per visit) */
     uint32_t orb_keypoints;      /* len(ORB_create().detectAndCompute(gray64)[0])  (:385-389)  */
     uint32_t orb_response;       /* FAST score of that keypoint, 0 when there is none       */
     uint32_t hyst_overflow;      /* 1 if the Canny hysteresis hit its round bound before the fixpoint:
@@ -147,6 +157,20 @@ VQA_API int vqa_destroy(vqa_ctx *ctx);
 /* text of the last failing HIP call on this ctx ("" if none) */
 VQA_API const char *vqa_last_hip_error(const vqa_ctx *ctx);
 VQA_API void vqa_default_params(vqa_params *p);
+/* 0 = the shipped library; bit 0 = built with the superseded A/B kernels, bit 1 = built with the test seams (lab build) */
+VQA_API int vqa_build_flavour(void);
+
+/* ---- per-ctx options (none of them changes a result) ------------------------ */
+enum vqa_option {
+    VQA_OPT_OVERLAP = 0,    /* 1 (default; initial value from VQA_OVERLAP if set): inside one complexity submit block-SAD
+                               and the Canny chain run on two side streams of the ctx next to DCT / ORB and join before
+                               the results are copied (+3 % on the full suite).  0: every kernel on the ctx stream in
+                               program order - per-kernel event times (vqa_profile_*) are then free of overlap          */
+    VQA_OPT_HYST_STATS = 1  /* 1: fill vqa_frame_metrics.hyst_steps (default 0)                                        */
+};
+/* VQA_ERR_STATE while a submit is pending on the ctx */
+VQA_API int vqa_set_option(vqa_ctx *ctx, int option, int value);
+VQA_API int vqa_get_option(const vqa_ctx *ctx, int option, int *value);
 
 /* ---- memory --------------------------------------------------------------- */
 VQA_API int vqa_alloc_pinned(vqa_ctx *ctx, size_t bytes, void **out);
@@ -169,7 +193,12 @@ VQA_API void *vqa_stream(vqa_ctx *ctx);
  * mem_kind) or NULL; frame i's "previous" is frame i-1.
  * Asynchronous: returns once the work is enqueued.  Limits: h*w <= 2^28 pixels
  * (VQA_ERR_UNSUPPORTED beyond); n is bounded by memory only (batches above 32768
- * frames are enqueued as consecutive slices internally).                       */
+ * frames are enqueued as consecutive slices internally).
+ * Failure: a submit that returns non-zero has left NOTHING in flight - whatever it had
+ * already enqueued has completed on every stream of the ctx before the call returns,
+ * no batch is pending, the caller's buffers are free again and the ctx stays usable
+ * (the reference's convention: log, re-raise, nothing left running,
+ * video_processing.py:295-297).  The same holds for vqa_quality_submit.          */
 VQA_API int vqa_complexity_submit(vqa_ctx *ctx, const uint8_t *frames, const uint8_t *prev0, int mem_kind,
                           int n, int h, int w, int64_t frame_stride, int64_t row_stride,
                           uint32_t metric_mask, const vqa_params *params);
@@ -222,10 +251,11 @@ VQA_API int vqa_comm_create_rank(vqa_ctx *ctx, const void *id, size_t id_bytes, 
 VQA_API int vqa_comm_destroy(vqa_comm *comm);
 VQA_API int vqa_comm_size(const vqa_comm *comm);           /* ranks in the communicator */
 VQA_API const char *vqa_comm_last_error(const vqa_comm *comm); /* comm == NULL: why this thread's last creation failed */
-/* Test seam.  With VQA_COMM_FAKE_RCCL=1 in the environment an in-library stand-in takes the place of the RCCL entry
- * points (it checks the group bracketing and sums on the host), which lets the single-process multi-context path run
- * on a one-GPU box; this returns the stand-in's call trace ("" otherwise).  Multi-device use over real RCCL has not
- * run on hardware yet (no multi-GPU box was available to the builder).                                              */
+/* Test seam, LAB BUILD ONLY (vqa_build_flavour() & 2).  There, with VQA_COMM_FAKE_RCCL=1 in the environment when the
+ * first communicator is made, an in-library stand-in takes the place of the RCCL entry points (it checks the group
+ * bracketing and sums on the host), which lets the single-process multi-context path run on a one-GPU box; this returns
+ * the stand-in's call trace.  The shipped library has no stand-in: it always returns "".  Multi-device use over real
+ * RCCL has not run on hardware yet (no multi-GPU box was available to the builder).                                  */
 VQA_API const char *vqa_comm_debug_trace(void);
 /* In place: vals is [local contexts][count] doubles, row i belongs to the i-th local
  * context (one row with vqa_comm_create_rank); on return every row holds the sum over

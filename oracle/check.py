@@ -14,6 +14,7 @@ from . import c_oracle as co
 from . import pipeline as pl
 
 RTOL = 1e-4
+FLOW_RTOL_BORDER = 2e-3  # include/vqa.h, flow_mag_mean: the bar on frames with a border pixel at the in-frame discontinuity
 
 
 def bgr_planes(h, w):
@@ -24,8 +25,9 @@ def expected(ref, dist, prev, full=True, ssim_modes=("gauss",), motion="sad", pl
              dct_mode="block8"):
     """ref, dist, prev: uint8 [h,w,3] BGR (ref/dist = the quality pair, prev = the frame before dist in the
     distorted stream); qpair = (ref, dist) buffers in another pixel format (yuv420p) with their `planes`.
-    dct_mode "full": only the Parseval known answer is checked for the energy and the temporal L1 is skipped
-    (the full-frame transform of a 1080p plane takes the oracle minutes).  -> dict of expected record fields."""
+    dct_mode "full": the energy is checked against the Parseval known answer, the temporal L1 against
+    scipy.fft.dctn(norm="ortho") in float64 (the C oracle's O(n^3) full-frame transform of a 1080p plane takes minutes;
+    the two agree to 1e-6 where both run, tests/test_oracle_kat.py).  -> dict of expected record fields."""
     h, w = dist.shape[:2]
     out = {}
     if ref is not None:
@@ -39,6 +41,9 @@ def expected(ref, dist, prev, full=True, ssim_modes=("gauss",), motion="sad", pl
     if dct_mode == "block8":
         e, l1, _ = co.dct8x8(gp, g)
         out["dct_energy"], out["temporal_dct_l1"] = float(e), float(l1)
+    elif gp is not None:
+        from scipy.fft import dctn
+        out["temporal_dct_l1"] = float(np.abs(dctn(gp.astype(np.float64), norm="ortho") - dctn(g.astype(np.float64), norm="ortho")).sum())
     out["sum_gray2"] = int((g.astype(np.int64) ** 2).sum())
     if full:
         cnt, strong, weak = co.canny(g, 100, 200)
@@ -59,9 +64,10 @@ def _rel(a, b):
     return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
 
 
-def compare(exp, crec=None, qrow=None, ssim_mode="gauss"):
+def compare(exp, crec=None, qrow=None, ssim_mode="gauss", notes=None):
     """Mismatches between the expected dict and one vqa_frame_metrics record / one row of vqa_plane_metrics.
-    -> list of strings (empty = the frame verifies)."""
+    -> list of strings (empty = the frame verifies).  notes (a list) receives a line for every field that only met a
+    documented looser bar (Farneback's border discontinuity)."""
     bad = []
     if qrow is not None and "sse" in exp:
         for p, (s, m) in enumerate(zip(exp["sse"], exp["ssim_" + ssim_mode])):
@@ -96,8 +102,11 @@ def compare(exp, crec=None, qrow=None, ssim_mode="gauss"):
             if not np.array_equal(crec["mv_d2_hist"], exp["mv_d2_hist"]):
                 bad.append("mv_d2_hist differs")
         else:
-            if _rel(crec["flow_mag_mean"], exp["flow_mag_mean"]) > RTOL:
+            r = _rel(crec["flow_mag_mean"], exp["flow_mag_mean"])
+            if r > FLOW_RTOL_BORDER:
                 bad.append("flow_mag_mean %.9g vs %.9g" % (float(crec["flow_mag_mean"]), exp["flow_mag_mean"]))
+            elif r > RTOL and notes is not None:  # both values are valid evaluations (include/vqa.h); say which bar held
+                notes.append("flow_mag_mean met %.0e, not %.0e (%.3g relative)" % (FLOW_RTOL_BORDER, RTOL, r))
         if not np.array_equal(crec["hist_gray"], exp["hist_gray"]):
             bad.append("hist_gray differs")
         if not np.array_equal(crec["hist_bgr"], exp["hist_bgr"]):

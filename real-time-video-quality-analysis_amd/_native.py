@@ -7,10 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VQA_LIB_PATH: load another build of the same ABI (A/B timing of two builds on one GPU box); default = the in-tree library
+# VQA_LIB_PATH: load another build of the same ABI (the lab build csrc/lab/libvqa_hip_lab.so for A/B re-measurement and
+# fault injection, or a probe build); default = the shipped in-tree library
 LIB_PATH = os.environ.get("VQA_LIB_PATH") or os.path.join(_HERE, "csrc", "libvqa_hip.so")
+LAB_LIB_PATH = os.path.join(_HERE, "csrc", "lab", "libvqa_hip_lab.so")
 
-VQA_ABI_VERSION = 4
+VQA_ABI_VERSION = 5
 
 VQA_OK = 0
 VQA_ERR_INVALID = -1
@@ -34,6 +36,9 @@ M_ALL = 0x7F
 
 (K_GRAY_HIST, K_RESIZE, K_DCT8, K_DCT_FULL, K_CANNY_NMS, K_CANNY_HYST, K_SAD, K_SSIM_GAUSS, K_SSIM_FFMPEG, K_ORB,
  K_FARNEBACK, K_COUNT) = range(12)
+
+OPT_OVERLAP, OPT_HYST_STATS = 0, 1
+FLAVOUR_AB_VARIANTS, FLAVOUR_TEST_SEAMS = 1, 2
 
 DCT_AUTO, DCT_BLOCK8, DCT_FULL = 0, 1, 2
 SSIM_GAUSS, SSIM_FFMPEG = 0, 1
@@ -84,6 +89,9 @@ SIGNATURES = {
     "vqa_destroy": (C.c_int, [C.c_void_p]),
     "vqa_last_hip_error": (C.c_char_p, [C.c_void_p]),
     "vqa_default_params": (None, [C.POINTER(VqaParams)]),
+    "vqa_build_flavour": (C.c_int, []),
+    "vqa_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "vqa_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "vqa_alloc_pinned": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vqa_free_pinned": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vqa_alloc_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -8,8 +8,9 @@
 //   k_canny_nms3 (default): lane = column; a vector compare of 64 columns IS a bit-plane word and every NMS decision is
 //     mask logic on the scalar unit; one unaligned dword load per pixel; v_sad_u32 magnitudes; DPP ring for the
 //     horizontal neighbours; lane r captures row r, so a strip leaves as four 512-byte tile stores (details below).
-//   k_canny_nms2 (VQA_NMS_VARIANT=2, round 2's kernel): 4 pixels per lane, packed 16-bit Sobel, register-rolling.
-//   k_canny_nms  (VQA_NMS_VARIANT=1, round 1's kernel): 64x32 tile per workgroup through LDS, words built with __ballot.
+//   k_canny_nms  (frames narrower than 4 pixels, which the dword window cannot serve): 64x32 tile per workgroup through
+//     LDS, words built with __ballot (round 1's kernel).
+//   k_canny_nms2 (lab build only, VQA_NMS_VARIANT=2: round 2's kernel): 4 pixels per lane, packed 16-bit Sobel.
 //   All: Sobel 3x3 on replicated borders, L1 magnitude = 0 outside the image (OpenCV's zero-bordered
 //   buffer), TG22 fixed-point sector test.
 // Stage 2 (k_canny_hyst_*): 8-connected hysteresis as an iterate-to-fixpoint on
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void k_canny_nms(const uint8_t *__restrict__ g
     }
 }
 
+#ifdef VQA_AB_VARIANTS // round 2's kernel, lab build only (VQA_NMS_VARIANT=2)
 // ---------------------------------------------------------------------------
 // Stage 1, register-rolling form (k_canny_nms2): no LDS, no barriers, no cross-lane traffic until the
 // bit-plane words are assembled.  A wave covers 256 columns and marches down a 64-row strip; every lane
@@ -304,6 +306,8 @@ __global__ __launch_bounds__(64) void k_canny_nms2(const uint8_t *__restrict__ g
     }
 }
 
+#endif // VQA_AB_VARIANTS
+
 // ---------------------------------------------------------------------------
 // Stage 1, lane-per-column form (k_canny_nms3, the default): a wave still covers 256 columns x a 64-row strip
 // (= 4 hysteresis tiles), but lane L owns the FOUR COLUMNS x0 + 64 k + L (k = 0..3), so the 64 lanes of group k
@@ -336,13 +340,17 @@ __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) 
 __device__ __forceinline__ uint32_t wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13C, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134, 0xf, 0xf, false); }
 
-// lane `lane` of `old` <- the wave-uniform `val`.  The lane select goes through M0: a VOP3 on gfx9 reads at most one
-// SGPR besides it.  (M0 is otherwise unused here: these kernels have no LDS / GDS traffic.)
-__device__ __forceinline__ void set_m0(int lane) { asm volatile("s_mov_b32 m0, %0" : : "s"(lane) : "m0"); }
-__device__ __forceinline__ uint32_t writelane_m0(uint32_t old, uint32_t val)
+// lane `lane` of (a, b) <- the wave-uniform words (lo, hi).  The lane select goes through M0 (a VOP3 on gfx9 reads at most
+// one SGPR besides it).  M0 is written and consumed INSIDE one asm statement that declares the clobber: the compiler can
+// neither schedule anything that touches M0 between the write and its readers nor assume M0 survives the statement
+// (round 3 set M0 in one asm and read it in others, which only held as long as the compiler emitted nothing
+// M0-related in between).
+__device__ __forceinline__ void writelane2(uint32_t &a, uint32_t &b, int lane, uint32_t lo, uint32_t hi)
 {
-    asm volatile("v_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val));
-    return old;
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
+                 : "+v"(a), "+v"(b)
+                 : "s"(lane), "s"(lo), "s"(hi)
+                 : "m0");
 }
 
 typedef unsigned long long u64;
@@ -446,9 +454,8 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const __amdgpu_b
         return;
     }
     // ---- per tile: finish the row above (it now has its lower neighbours), prepare the new row.  The scalar unit
-    // (one per CU, shared by the four SIMDs) is this kernel's scarcest resource: no per-class branches, M0 set once
-    const int yout = yy - 1 - y0; // strip row finished by this step
-    if (yout >= 0) set_m0(yout);  // wave-uniform; lane yout captures its row
+    // (one per CU, shared by the four SIMDs) is this kernel's scarcest resource: no per-class branches
+    const int yout = yy - 1 - y0; // strip row finished by this step (wave-uniform); lane yout captures its row
     u64 ST_new[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -459,8 +466,7 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const __amdgpu_b
         const u64 keep = S.HH[k] | (S.VV[k] & ~gt) | (S.DS[k] & __ballot(m2 > m1R)) | (S.DO[k] & __ballot(m2 > m1L));
         if (NMS3_PROBE == 1) { S.cs[k][0] += (uint32_t)keep; S.cw[k][0] += (uint32_t)(keep >> 32); }
         else if (yout >= 0) { // lane yout captures the row's kept pixels (its above-high word was captured a step ago)
-            S.cs[k][0] = writelane_m0(S.cs[k][0], (uint32_t)keep);
-            S.cs[k][1] = writelane_m0(S.cs[k][1], (uint32_t)(keep >> 32));
+            writelane2(S.cs[k][0], S.cs[k][1], yout, (uint32_t)keep, (uint32_t)(keep >> 32));
         }
         // new row as the centre: direction sectors, same-row and upward compares
         u64 cand = __ballot((int)m1 > low);
@@ -483,14 +489,11 @@ __device__ __forceinline__ void nms3_step(nms3_state &S, int j, const __amdgpu_b
         }
         S.HH[k] = HH; S.VV[k] = VV; S.DO[k] = DO; S.DS[k] = DS; ST_new[k] = ST;
     }
-    // the new row's above-high words go to lane yout + 1 now: one more M0 write per step, 8 scalar registers fewer to carry
+    // the new row's above-high words go to lane yout + 1 now (8 scalar registers fewer to carry into the next step)
     if (NMS3_PROBE != 1 && yout + 1 >= 0 && yout + 1 < 64) {
-        set_m0(yout + 1);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            S.cw[k][0] = writelane_m0(S.cw[k][0], (uint32_t)ST_new[k]);
-            S.cw[k][1] = writelane_m0(S.cw[k][1], (uint32_t)(ST_new[k] >> 32));
-        }
+        for (int k = 0; k < 4; k++)
+            writelane2(S.cw[k][0], S.cw[k][1], yout + 1, (uint32_t)ST_new[k], (uint32_t)(ST_new[k] >> 32));
     }
 }
 
@@ -615,7 +618,8 @@ __device__ __forceinline__ row64 operator|(row64 a, row64 b) { return row64{a.lo
 // a | (m & t): one v_and_or_b32 per half
 __device__ __forceinline__ row64 and_or(row64 m, row64 t, row64 a) { return row64{(m.lo & t.lo) | a.lo, (m.hi & t.hi) | a.hi}; }
 
-// occluded fill along a row: every run of `pro` cells touching a `gen` cell becomes gen
+#ifdef VQA_AB_VARIANTS
+// (round 2's ladder) occluded fill along a row: every run of `pro` cells touching a `gen` cell becomes gen
 __device__ __forceinline__ row64 flood_row(row64 gen, row64 pro)
 {
     row64 a = gen, m = pro;
@@ -642,6 +646,7 @@ __device__ __forceinline__ row64 dil3(row64 s, uint32_t l, uint32_t r)
     const row64 sl = shl<1>(s), sr = shr<1>(s);
     return row64{s.lo | sl.lo | sr.lo | l, s.hi | sl.hi | sr.hi | (r << 31)};
 }
+#endif
 
 // lane i <- lane i-1 (lane 0 keeps its own) / lane i <- lane i+1 (lane 63 keeps its own): whole-wave DPP shifts
 // (wave_shr:1 / wave_shl:1, one vector-ALU instruction) instead of ds_bpermute round trips through the LDS pipe -
@@ -724,11 +729,15 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
     uint32_t dn_l = lane_dn32(hl32), dn_r = lane_dn32(hr32);
     if (lane == 0) { up_l = (uint32_t)el; up_r = (uint32_t)er; }
     if (lane == 63) { dn_l = (uint32_t)el; dn_r = (uint32_t)er; }
-    const row64 wr = to_row(w), F = to_row(s0 | w), esr = to_row(es);
+    [[maybe_unused]] const row64 wr = to_row(w), F = to_row(s0 | w); // (the lab build's ladder)
+    const row64 esr = to_row(es);
     row64 sr = to_row(s0);
     unsigned steps = 0;
-    if (A.sub == 0) {
-        // Default schedule.  One iteration = ONE 3x3 dilation step (rows above/below by whole-wave DPP shifts whose
+#ifdef VQA_AB_VARIANTS
+    if (A.sub == 0)
+#endif
+    {
+        // The schedule.  One iteration = ONE 3x3 dilation step (rows above/below by whole-wave DPP shifts whose
         // `old` operand supplies the halo row to lane 0 / lane 63, then a 3-wide horizontal dilation of the OR of the
         // three rows) followed by a flood along the rows done by the integer adder: for seeds S inside a mask F of
         // runs, F + S carries from every seed to the end of its run, so (F & ~(F + S)) | S is the run filled from the
@@ -754,8 +763,10 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
             cur = (F64 & ~(F64 + seed)) | __builtin_bitreverse64(rF64 & ~(rF64 + rs)) | seed;
         }
         sr = to_row(cur);
-    } else {
-        // One iteration = A.sub cheap sub-steps (each: rows above/below by lane shift, 3-wide dilation, promote the weak
+    }
+#ifdef VQA_AB_VARIANTS
+    else {
+        // (round 2's schedule) One iteration = A.sub cheap sub-steps (each: rows above/below by lane shift, 3-wide dilation, promote the weak
         // cells that touch an edge cell: a chain advances one row per sub-step, diagonals included) followed by ONE
         // Kogge-Stone flood along the rows.  Promotion is monotone, so any schedule reaches the same fixpoint; a chain
         // that runs down the tile costs ~45 instructions per row instead of a whole flood (~130) per row.
@@ -776,9 +787,10 @@ __device__ __forceinline__ void relax_tile(const hyst_args &A, unsigned tile)
             sr = flood_row(sr, F);
         }
     }
+#endif
     const u64 s = to_u64(sr);
     const u64 promoted = s & ~s0;
-    if (A.stats && lane == 0) atomicAdd(&A.res[f].hyst_steps, steps); // diagnostic, VQA_HYST_STATS=1 only
+    if (A.stats && lane == 0) atomicAdd(&A.res[f].hyst_steps, steps); // diagnostic, VQA_OPT_HYST_STATS only
     if (!__any(promoted != 0)) return; // nothing changed: nothing to store, nobody to wake
     if (promoted) A.strong[idx] = s;   // (the edge pixels are counted once, from the final plane: k_canny_count)
     // Which neighbours must be re-visited: those holding a candidate pixel 8-adjacent to a promoted one.
@@ -929,39 +941,35 @@ void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t pl
                       vqa_frame_metrics *res)
 {
     if (n <= 0) return;
-    // A/B knob (VQA_NMS_VARIANT): 3 = lane-per-column kernel (default), 2 = 4-pixels-per-lane register-rolling kernel
-    // (round 2's default), 1 = LDS-tile kernel (round 1)
-    static int variant = -1;
-    if (variant < 0) { const char *e = getenv("VQA_NMS_VARIANT"); variant = e ? atoi(e) : 3; }
-    if (variant == 3 && w >= 4) { // (the dword window needs 4 columns; narrower frames take the byte-load kernel)
+    // w < 4: the dword window of k_canny_nms3 needs 4 columns; such slivers take the LDS-tile kernel.
+    // Lab build (VQA_NMS_VARIANT): 3 = lane-per-column kernel (shipped), 2 = round 2's register-rolling kernel, 1 = LDS tiles
+    static const int variant = ab_knob("VQA_NMS_VARIANT", 3);
+    if (variant == 3 && w >= 4) {
         const int sx = (w + 255) / 256, sy = (h + 63) / 64;
         const long long ns = (long long)sx * sy * n; // (n <= 32768 per launch: fits an int)
         hipLaunchKernelGGL(k_canny_nms3, dim3((unsigned)(8 * ((ns + 7) / 8))), dim3(64), 0, st, gray, pitch,
                            plane_stride, h, w, low, high, strong, weak, (w + 63) / 64, res, sx, sy, (int)ns);
-    } else if (variant == 1) {
+#ifdef VQA_AB_VARIANTS
+    } else if (variant == 2) {
+        hipLaunchKernelGGL(k_canny_nms2, dim3((w + 255) / 256, (h + 63) / 64, n), dim3(64), 0, st, gray, pitch,
+                           plane_stride, h, w, low, high, strong, weak, (w + 63) / 64, res);
+#endif
+    } else {
         const canny_geom g = canny_tiles(h, w);
         hipLaunchKernelGGL(k_canny_nms, dim3(g.tiles_x, g.tiles_y, n), dim3(256), 0, st, gray, pitch, plane_stride, h, w,
                            low, high, strong, weak, (w + 63) / 64, res);
-    } else {
-        hipLaunchKernelGGL(k_canny_nms2, dim3((w + 255) / 256, (h + 63) / 64, n), dim3(64), 0, st, gray, pitch,
-                           plane_stride, h, w, low, high, strong, weak, (w + 63) / 64, res);
     }
 }
 
 static hyst_args make_hyst_args(unsigned long long *strong, const unsigned long long *weak, int h, int w,
-                                unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res)
+                                unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res, int stats)
 {
     hyst_args A;
     A.strong = strong; A.weak = weak; A.h = h; A.ww = (w + 63) / 64; A.tiles_y = (h + 63) / 64;
     A.queued = queued; A.out_list = out_list; A.out_count = out_count; A.res = res;
-    static int sub = 0;
-    if (!sub) { // A/B knob VQA_HYST_SUB (1 = one vertical step per flood, the round-1 schedule)
-        const char *e = getenv("VQA_HYST_SUB");
-        sub = (e && atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0; // 0 = dilation + carry flood (default); 1..8 = round 2's ladder
-    }
+    // 0 = dilation + carry flood (shipped); lab build, VQA_HYST_SUB=1..8: round 2's shift/and/or ladder with that many sub-steps
+    static const int sub = [] { const int e = ab_knob("VQA_HYST_SUB", 0); return (e >= 1 && e <= 8) ? e : 0; }();
     A.sub = sub;
-    static int stats = -1;
-    if (stats < 0) { const char *e = getenv("VQA_HYST_STATS"); stats = (e && atoi(e) > 0) ? 1 : 0; }
     A.stats = stats;
     return A;
 }
@@ -969,18 +977,19 @@ static hyst_args make_hyst_args(unsigned long long *strong, const unsigned long 
 unsigned canny_hyst_tiles(int n, int h, int w) { return (unsigned)n * ((h + 63) / 64) * ((w + 63) / 64); }
 
 void launch_canny_hyst_all(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
-                           int w, unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res)
+                           int w, unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res,
+                           int stats)
 {
     if (n <= 0) return;
     const unsigned nt = canny_hyst_tiles(n, h, w);
     hipLaunchKernelGGL(k_canny_hyst_all, dim3(8 * (((nt + 3) / 4 + 7) / 8)), dim3(256), 0, st,
-                       make_hyst_args(strong, weak, h, w, queued, out_list, out_count, res), nt);
+                       make_hyst_args(strong, weak, h, w, queued, out_list, out_count, res, stats), nt);
 }
 
 void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *in_queued, const unsigned *in_list, const unsigned *in_count,
                             unsigned *out_queued, unsigned *out_list, unsigned *out_count, unsigned *zero_count,
-                            vqa_frame_metrics *res)
+                            vqa_frame_metrics *res, int stats)
 {
     if (n <= 0) return;
     // workgroups per frame: ~64 tiles of the frame per 4-wave workgroup (1080p: 8, 2160p: 32)
@@ -988,7 +997,7 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
     int gx = (g.tiles_x * g.tiles_y + 63) / 64;
     gx = gx < 8 ? 8 : (gx > 32 ? 32 : gx);
     hipLaunchKernelGGL(k_canny_hyst_list, dim3(gx, n), dim3(256), 0, st,
-                       make_hyst_args(strong, weak, h, w, out_queued, out_list, out_count, res), in_list, in_count,
+                       make_hyst_args(strong, weak, h, w, out_queued, out_list, out_count, res, stats), in_list, in_count,
                        in_queued, zero_count);
 }
 
@@ -996,16 +1005,12 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
 // per-frame work lists; first_in = index of the list the first tail round consumes.
 void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *list0, unsigned *cnt0, unsigned *q0, unsigned *list1, unsigned *cnt1,
-                            unsigned *q1, int first_in, vqa_frame_metrics *res)
+                            unsigned *q1, int first_in, vqa_frame_metrics *res, int stats, int max_rounds)
 {
     if (n <= 0) return;
-    static int max_rounds = 0;
-    if (!max_rounds) { // VQA_HYST_MAX_ROUNDS: test hook for the overflow flag
-        const char *e = getenv("VQA_HYST_MAX_ROUNDS");
-        max_rounds = (e && atoi(e) > 0) ? atoi(e) : (1 << 16);
-    }
+    if (max_rounds <= 0) max_rounds = CANNY_HYST_MAX_ROUNDS;
     hipLaunchKernelGGL(k_canny_hyst_tail, dim3(n), dim3(1024), 0, st,
-                       make_hyst_args(strong, weak, h, w, nullptr, nullptr, nullptr, res), list0, cnt0, q0, list1, cnt1,
+                       make_hyst_args(strong, weak, h, w, nullptr, nullptr, nullptr, res, stats), list0, cnt0, q0, list1, cnt1,
                        q1, first_in, max_rounds);
 }
 

@@ -23,6 +23,7 @@
 
 namespace vqa {
 
+#ifdef VQA_AB_VARIANTS // round 1's kernels (two transforms per pair), lab build only: VQA_DCT_VARIANT=1..4
 __device__ __forceinline__ void load_block_u8(const uint8_t *__restrict__ plane, int pitch, int h, int w, int by,
                                               int bx, uint32_t lo[8], uint32_t hi[8])
 {
@@ -159,8 +160,10 @@ __global__ __launch_bounds__(256, 2) void k_dct8_pair(const uint8_t *__restrict_
     }
 }
 
+#endif // VQA_AB_VARIANTS
+
 // ---------------------------------------------------------------------------
-// Frame-marching form (default).  The reference's temporal metric is dct(prev) - dct(curr)
+// Frame-marching form (the shipped kernel).  The reference's temporal metric is dct(prev) - dct(curr)
 // (complexity_metrics.py:574-578): consecutive pairs share a transform, DCT(curr_t) IS DCT(prev_{t+1}).
 // So a lane keeps ONE 8x8 block position and marches through a chunk of consecutive frames, carrying
 // the 64 coefficients of the previous frame in registers: one 2-D transform per frame instead of two,
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(64) void k_dct_finalize2(const float2 *__restrict__
     }
 }
 
+#ifdef VQA_AB_VARIANTS
 // Deterministic second stage: one thread per frame adds the per-block partials
 // in a fixed order and stores them into the result records.
 __global__ void k_dct_finalize(const double *__restrict__ partials, int pb, int n, vqa_frame_metrics *__restrict__ res,
@@ -411,24 +415,26 @@ static int dct8_blocks_legacy(int h, int w)
     return pb < 1 ? 1 : (pb > 64 ? 64 : pb);
 }
 
+#endif // VQA_AB_VARIANTS
+
 // 16-byte partial slots per frame the DCT launch needs (sizes the scratch buffer): the marching kernel writes one
-// float2 per wave of 64 block positions, the legacy kernel two doubles per workgroup
+// float2 per wave of 64 block positions (the lab build's legacy kernels: two doubles per workgroup)
 int dct8_blocks_per_frame(int h, int w)
 {
     const int nblk = ((w + 7) / 8) * ((h + 7) / 8);
     const int nw = (nblk + 63) / 64;
+#ifdef VQA_AB_VARIANTS
     const int legacy = dct8_blocks_legacy(h, w);
     return (nw + 1) / 2 > legacy ? (nw + 1) / 2 : legacy;
+#else
+    return (nw + 1) / 2;
+#endif
 }
 
+#ifdef VQA_AB_VARIANTS
 static int dct_variant()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("VQA_DCT_VARIANT");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 4) v = 0;
-    }
+    static const int v = [] { const int e = ab_knob("VQA_DCT_VARIANT", 0); return (e < 0 || e > 4) ? 0 : e; }();
     return v;
 }
 
@@ -448,13 +454,15 @@ static void launch_dct8_v(hipStream_t st, dim3 grid, const uint8_t *planes, int 
                            (int)first_has_prev, partials);
 }
 
+#endif // VQA_AB_VARIANTS
+
 // frames per chunk of the marching kernel: every chunk pays one halo transform (1/chunk of extra work); more, smaller
 // chunks give the dispatcher finer grains at the tail of the grid.  Measured on 256 x 1080p and 64 x 2160p: 12..24
 // frames per chunk are within 2 % of each other and 3-5 % better than one grid-filling round of 43; so: 16, shrunk
 // until the grid has at least two waves per wave slot of the chip.
 static int dct_march_chunk(int n, int nw)
 {
-    if (const char *e = getenv("VQA_DCT_FCH")) { const int v = atoi(e); if (v > 0) return v < n ? v : n; } // tuning knob
+    { static const int v = ab_knob("VQA_DCT_FCH", 0); if (v > 0) return v < n ? v : n; } // lab build: tuning knob
     static int slots = 0;
     if (!slots) {
         int dev = 0, cus = 256, per_cu = 3;
@@ -473,13 +481,17 @@ void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane
                  bool energy, bool temporal, bool first_has_prev, double *partials, vqa_frame_metrics *res)
 {
     if (n <= 0 || (!energy && !temporal)) return;
-    if (dct_variant() == 0) { // frame-marching kernel: one transform per frame
+#ifdef VQA_AB_VARIANTS
+    if (dct_variant() == 0)
+#endif
+    { // frame-marching kernel: one transform per frame
         const int nblk = ((w + 7) / 8) * ((h + 7) / 8), nw = (nblk + 63) / 64;
         const int fch = dct_march_chunk(n, nw);
         dim3 grid((nw + 3) / 4, (n + fch - 1) / fch);
         float2 *p2 = (float2 *)partials;
         const bool ragged = ((w | h) & 7) != 0;
-        static const bool early = getenv("VQA_DCT_LOAD_EARLY") && atoi(getenv("VQA_DCT_LOAD_EARLY")) != 0; // A/B knob
+#ifdef VQA_AB_VARIANTS
+        static const bool early = ab_knob("VQA_DCT_LOAD_EARLY", 0) != 0;
 #define LAUNCH_MARCH(E, T, R)                                                                                             \
     do {                                                                                                                  \
         if (early)                                                                                                        \
@@ -489,6 +501,11 @@ void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane
             hipLaunchKernelGGL((k_dct8_march<E, T, R, false>), grid, dim3(256), 0, st, planes, pitch, plane_stride, h, w, \
                                n, fch, nw, (int)first_has_prev, p2);                                                        \
     } while (0)
+#else
+#define LAUNCH_MARCH(E, T, R)                                                                                             \
+    hipLaunchKernelGGL((k_dct8_march<E, T, R, false>), grid, dim3(256), 0, st, planes, pitch, plane_stride, h, w, n, fch,  \
+                       nw, (int)first_has_prev, p2)
+#endif
         if (energy && temporal) { if (ragged) LAUNCH_MARCH(true, true, true); else LAUNCH_MARCH(true, true, false); }
         else if (energy) { if (ragged) LAUNCH_MARCH(true, false, true); else LAUNCH_MARCH(true, false, false); }
         else { if (ragged) LAUNCH_MARCH(false, true, true); else LAUNCH_MARCH(false, true, false); }
@@ -497,7 +514,8 @@ void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane
                            (int)first_has_prev);
         return;
     }
-    // legacy kernels (A/B: VQA_DCT_VARIANT 1, 2, 4 = two transforms per pair at min 1 / 4 / 3 waves per SIMD; 3 = float2-paired)
+#ifdef VQA_AB_VARIANTS
+    // legacy kernels (VQA_DCT_VARIANT 1, 2, 4 = two transforms per pair at min 1 / 4 / 3 waves per SIMD; 3 = float2-paired)
     const int pb = dct8_blocks_legacy(h, w);
     for (int a = 0; a < n; a += 65535) { // frames ride in gridDim.y
         const int m = n - a < 65535 ? n - a : 65535;
@@ -518,6 +536,7 @@ void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane
         hipLaunchKernelGGL(k_dct_finalize, dim3((m + 63) / 64), dim3(64), 0, st, pp, pb, m, res + a, (int)energy,
                            (int)temporal, (int)fhp);
     }
+#endif // VQA_AB_VARIANTS
 }
 
 } // namespace vqa

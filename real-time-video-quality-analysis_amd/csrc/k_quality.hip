@@ -5,8 +5,10 @@
 //
 //   k_ssim_gauss : SSE + Gaussian-windowed SSIM (11x11, sigma 1.5, K1 .01, K2 .03,
 //                  valid region) — the window BASELINE.json's north_star decrees.
-//   k_ssim_ffmpeg: SSE + FFmpeg vf_ssim's integer 8x8-window / stride-4 SSIM — what
-//                  the reference's subprocess actually computes (:276).
+//   k_ssim_ffmpeg_fast / k_ssim_ffmpeg: SSE + FFmpeg vf_ssim's integer 8x8-window / stride-4 SSIM — what
+//                  the reference's subprocess actually computes (:276).  _fast (dword loads + v_dot4) serves
+//                  4-byte-aligned planar planes and packed BGR24; the byte kernel is the general path for
+//                  every other layout (odd offsets / strides, other pixel steps) — not an A/B variant.
 //
 // k_ssim_gauss design.  The separable window needs 2 x 11 taps on 4 moment maps
 // (E[x], E[y], E[x^2+y^2], E[xy]) = 88 FMA per pixel, ~115 VALU ops per pixel
@@ -46,7 +48,10 @@ static inline int ssim_strips(int h, long long groups /* workgroups per strip ro
     const int cap = ssim_max_strips(h);
     return ns > cap ? cap : ns;
 }
-static inline int ssim_strip_rows(int h, int ns) { return (h - 10 + ns - 1) / ns; }
+// rows a strip owns: a multiple of 11 (k_ssim_gauss consumes rows in groups of 11 and owns whole groups)
+// rows a strip owns: a multiple of 22 (k_ssim_gauss_p2 consumes rows in groups of 22 and owns whole groups; the lab
+// build's one-row kernel needs a multiple of 11)
+static inline int ssim_strip_rows(int h, int ns) { return ((h - 10 + ns - 1) / ns + 21) / 22 * 22; }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -65,6 +70,10 @@ __host__ __device__ constexpr float gw(int k)
 // o0 = (mx, my): means of (x-128), (y-128); o1 = (sq, xy) = (E[(x-128)^2 + (y-128)^2], E[(x-128)(y-128)]).
 // Written on register PAIRS so the whole formula is 13 vector instructions: the (den, num) factors of the
 // luminance and the contrast/structure terms ride in the two halves of packed operations.
+// The uncentred means u = m + 128 ARE formed (exactly: |m| <= 128): round 4 tried ux uy = mx my + 128 (mx + my) + 128^2
+// to save three instructions and lost the 1e-4 bar on full-white against full-black (2.5e-4: the luminance numerator
+// 2 ux uy + C1 = 6.5 came out of terms of size 32768) - caught by tests/golden/skimage_pins.json, and the kernel is
+// power-bound, not issue-bound, so the instructions bought nothing (LAB_NOTES.md).
 __device__ __forceinline__ float ssim_centered(f2 o0, f2 o1)
 {
     const float C1 = 6.5025f, C2 = 58.5225f;
@@ -91,13 +100,22 @@ struct plane_group {
     int count;
 };
 
+#ifdef VQA_AB_VARIANTS // round 3's kernel (one row per barrier): lab build only
 // One column per thread; the four moment maps ride in two float2 registers
 // (E[x],E[y]) and (E[x^2+y^2],E[xy]), so every tap is two v_pk_fma_f32.  The rolling
 // accumulator file is 11 slots x 2 float2 = 44 VGPRs (80 VGPRs in all: 6 waves/SIMD).
 // PF = how many rows ahead the pixel loads run.
 // grid = (ncb * nstrips * group.count, n_frames)
+#ifndef SSIM_PROBE
+#define SSIM_PROBE 0   // measurement builds only (scripts/build_probes.sh SSIM_PROBE 1 2 3 ...): see LAB_NOTES.md
+#endif
+#if SSIM_PROBE == 3
+#define SSIM_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define SSIM_WAVES
+#endif
 template <int QT, int PF, int HPF>
-__global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dist,
+__global__ __launch_bounds__(QT) SSIM_WAVES void k_ssim_gauss(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dist,
                                                    int64_t ref_fs, int64_t dist_fs, plane_group g, int64_t row_stride,
                                                    int step, int w, int h, int ncb, int nstrips, int QS,
                                                    double *__restrict__ partials, int64_t partial_plane_stride,
@@ -135,93 +153,273 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss(const uint8_t *__restrict__ r
     for (int s = 0; s < 11; s++) acc[s] = f4{0.f, 0.f, 0.f, 0.f};
     float ssim_acc = 0.f;
     uint32_t sse_acc = 0;
+    // SSE = sum (x - y)^2 = sum (x^2 + y^2) - 2 sum x y, from the centred moments already in registers: two FMAs per
+    // pixel, exact in fp32 (integer sums below 2^24: flushed into sse_acc every 242 rows)
+    float sse_sq = 0.f, sse_xy = 0.f;
+    float own_f = own_c ? 1.f : 0.f;   // 0: a halo column (it belongs to the right neighbour block) or, below, a halo row
 
-    // Pixel loads run PF rows ahead of the arithmetic.  They are BUFFER loads: a scalar resource per plane, the
-    // lane's constant column offset as the vector offset and the row offset in a scalar register, so the vector ALUs
-    // spend nothing on addresses (the global_load form cost one v_lshl_add_u64 per load).  The queue of PF byte pairs
-    // is indexed statically: the row loop is unrolled over 22 rows (two turns of the 11-slot accumulator ring), so
-    // the slot (row mod PF) is a compile-time constant for PF = 1, 2 and no register is shifted.
-    static_assert(PF == 1 || PF == 2, "the 22-row unroll makes row mod PF static for PF = 1, 2");
+    // Pixel loads run one row ahead of the arithmetic (PF; depths 1..4 measured the same).  They are BUFFER loads: a
+    // scalar resource per plane, the lane's constant column offset as the vector offset and the row offset in a scalar
+    // register, so the vector ALUs spend nothing on addresses (the global_load form cost one v_lshl_add_u64 per load).
+    static_assert(PF == 1 || PF == 2, "prefetch depth");
     const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void *)rbase, (short)0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void *)dbase, (short)0, -1, 0x00020000);
     auto ld = [&](const __amdgpu_buffer_rsrc_t &rs, int rr) -> uint32_t {
         return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, coff, (int)((int64_t)rr * row_stride), 0);
     };
-    uint32_t qr[PF], qd[PF];
+    uint32_t nr = ld(rres, 0), nd = ld(dres, 0);   // row 0; row r + 1 is requested while row r is being consumed
+
+    // One input row: p = r mod 11 (a compile-time constant after unrolling: static accumulator slots), emit = the row
+    // completes an output row (r >= 10; wave-uniform).
+    auto row = [&](const int p, const int r, const bool emit) {
+        const uint32_t cr = nr, cd = nd;
+        {
+            const int rr = min(r + 1, nrows - 1);
+            nr = ld(rres, rr);
+            nd = ld(dres, rr);
+        }
+        // u8 -> centred float without a conversion instruction: 0x4B000000 | v is the float 2^23 + v, and
+        // subtracting 2^23 + 128 is exact (v_or_b32 + v_sub_f32 issue at full rate, v_cvt_f32_ubyte at half)
+        const f2 xy = f2{__uint_as_float(0x4B000000u | cr), __uint_as_float(0x4B000000u | cd)} - f2{8388736.f, 8388736.f};
+        f2 v1 = xy.xx * xy;              // (x^2, x y)
+        v1.x = fmaf(xy.y, xy.y, v1.x);   // (x^2 + y^2, x y): one scalar FMA, no operand repacking
+        sse_sq = fmaf(own_f, v1.x, sse_sq);
+        sse_xy = fmaf(own_f, v1.y, sse_xy);
+        // vertical pass: input row r is tap k of output row r-k, kept in slot (r-k) mod 11
 #pragma unroll
-    for (int i = 0; i < PF; i++) {
-        const int rr = min(i, nrows - 1);
-        qr[i] = ld(rres, rr);
-        qd[i] = ld(dres, rr);
-    }
-    for (int r0 = 0; r0 < nrows; r0 += 22) {
+        for (int k = 0; k < 11; k++) {
+            const int s = (p - k + 11) % 11;
+            if (k == 0) {
+                acc[s].xy = gw(0) * xy;
+                acc[s].zw = gw(0) * v1;
+            } else {
+                acc[s].xy = __builtin_elementwise_fma(f2{gw(k), gw(k)}, xy, acc[s].xy);
+                acc[s].zw = __builtin_elementwise_fma(f2{gw(k), gw(k)}, v1, acc[s].zw);
+            }
+        }
+        if (emit) {
+            const int s = (p + 1) % 11; // slot of output row o = r - 10, now complete
+            const int buf = (r - 10) & 1;
+            *(f4 *)&vb[buf][t] = acc[s];
+            __syncthreads();
+            if (out_c) {
+                f2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
+                if (HPF == 0) {
 #pragma unroll
-        for (int p2 = 0; p2 < 22; p2++) {
-            const int p = p2 % 11;
-            const int r = r0 + p2;
-            if (r < nrows) {
-                const uint32_t cr = qr[p2 % PF], cd = qd[p2 % PF];
-                {
-                    const int rr = min(r + PF, nrows - 1);
-                    qr[p2 % PF] = ld(rres, rr);
-                    qd[p2 % PF] = ld(dres, rr);
-                }
-                if (own_c && (last_sb || r < QS)) {
-                    const int e = (int)cr - (int)cd;
-                    sse_acc += (uint32_t)__mul24(e, e);
-                }
-                const f2 xy = f2{(float)cr, (float)cd} - f2{128.f, 128.f};
-                f2 v1 = xy.xx * xy;              // (x^2, x y)
-                v1.x = fmaf(xy.y, xy.y, v1.x);   // (x^2 + y^2, x y): one scalar FMA, no operand repacking
-                // vertical pass: input row r is tap k of output row r-k, kept in slot (r-k) mod 11
-#pragma unroll
-                for (int k = 0; k < 11; k++) {
-                    const int s = (p - k + 11) % 11;
-                    if (k == 0) {
-                        acc[s].xy = gw(0) * xy;
-                        acc[s].zw = gw(0) * v1;
-                    } else {
-                        acc[s].xy = __builtin_elementwise_fma(f2{gw(k), gw(k)}, xy, acc[s].xy);
-                        acc[s].zw = __builtin_elementwise_fma(f2{gw(k), gw(k)}, v1, acc[s].zw);
+                    for (int k = 0; k < 11; k++) {
+#if SSIM_PROBE == 1   // no LDS reads: the lane's own vertical sums stand in for its neighbours' (wrong numbers)
+                        const float4 q = make_float4(acc[s].x, acc[s].y, acc[s].z, acc[s].w);
+#elif SSIM_PROBE == 2 // 6 LDS reads instead of 11 (what a column-pair kernel would issue), same FMAs (wrong numbers)
+                        const float4 q = vb[buf][t + (k >> 1)];
+#else
+                        const float4 q = vb[buf][t + k];
+#endif
+                        o0 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.x, q.y}, o0);
+                        o1 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.z, q.w}, o1);
                     }
-                }
-                if (r >= 10) {
-                    const int s = (p + 1) % 11; // slot of output row o = r - 10, now complete
-                    const int buf = (r - 10) & 1;
-                    *(f4 *)&vb[buf][t] = acc[s];
-                    __syncthreads();
-                    if (out_c) {
-                        f2 o0 = {0.f, 0.f}, o1 = {0.f, 0.f};
-                        if (HPF == 0) {
+                } else {
+                    // (lab build) issue the LDS reads in groups of HPF before any arithmetic on them
+                    float4 q[11];
 #pragma unroll
-                            for (int k = 0; k < 11; k++) {
-                                const float4 q = vb[buf][t + k];
-                                o0 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.x, q.y}, o0);
-                                o1 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q.z, q.w}, o1);
-                            }
-                        } else {
-                            // issue the LDS reads in groups of HPF before any arithmetic on them: the
-                            // default schedule keeps only ~2 reads in flight and eats LDS latency 5x per row
-                            float4 q[11];
+                    for (int k0 = 0; k0 < 11; k0 += HPF) {
 #pragma unroll
-                            for (int k0 = 0; k0 < 11; k0 += HPF) {
+                        for (int k = k0; k < k0 + HPF && k < 11; k++) q[k] = vb[buf][t + k];
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int k = k0; k < k0 + HPF && k < 11; k++) q[k] = vb[buf][t + k];
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int k = k0; k < k0 + HPF && k < 11; k++) {
-                                    o0 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q[k].x, q[k].y}, o0);
-                                    o1 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q[k].z, q[k].w}, o1);
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
+                        for (int k = k0; k < k0 + HPF && k < 11; k++) {
+                            o0 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q[k].x, q[k].y}, o0);
+                            o1 = __builtin_elementwise_fma(f2{gw(k), gw(k)}, f2{q[k].z, q[k].w}, o1);
                         }
-                        ssim_acc += ssim_centered(o0, o1);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                ssim_acc += ssim_centered(o0, o1);
+            }
+        }
+    };
+
+    // Rows are consumed in groups of 11 (one turn of the accumulator ring).  The host picks QS as a multiple of 11, so the
+    // QS rows a strip OWNS (for the squared error) are exactly its full groups; what remains - the 10 halo rows shared
+    // with the next strip, or the last strip's leftover - goes through one guarded copy of the group below the loop.
+    // The main loop carries no per-row guards (round 3's single 22-row body tested r < nrows in every row, and the
+    // compiler paid for the merged control flow with four register moves per row).
+    const int nfull = nrows / 11;
+    int flush = 0;
+    for (int g = 0; g < nfull; g++) {
+        const int r0 = g * 11;
+        if (++flush == 22) { sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy); sse_sq = sse_xy = 0.f; flush = 0; } // 242 rows
+#pragma unroll
+        for (int pp = 0; pp < 11; pp++) row(pp, r0 + pp, pp == 10 || g > 0);
+    }
+    sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy);
+    sse_sq = sse_xy = 0.f;
+    if (!last_sb) own_f = 0.f; // the halo rows belong to the next strip
+    {
+        const int r0 = nfull * 11;
+#pragma unroll
+        for (int pp = 0; pp < 10; pp++)
+            if (r0 + pp < nrows) row(pp, r0 + pp, r0 + pp >= 10);
+    }
+    sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy);
+    const double bs = block_sum((double)ssim_acc, red);
+    const unsigned long long be = block_sum_u64((unsigned long long)sse_acc, redu);
+    if (t == 0) {
+        const int pidx = g.plane_index[ch];
+        partials[(int64_t)pidx * partial_plane_stride + (int64_t)f * bpp + tile] = bs;
+        if (be) atomicAdd((unsigned long long *)&res[(int64_t)f * n_planes + pidx].sse, be);
+    }
+}
+
+#endif // VQA_AB_VARIANTS
+
+// ---------------------------------------------------------------------------
+// k_ssim_gauss_p2: the same arithmetic with HALF the LDS read traffic.  Round 4 found the kernel power-bound (the
+// chip sits at its ~1.27 kW cap and sets the clock accordingly; removing 7 % of the instructions changed nothing),
+// with the 11 ds_read_b128 per pixel worth 19 % of a launch's energy (LAB_NOTES.md, profiles/round4_ssim_clock.json).
+// Here TWO rows go through LDS per barrier and a LANE PAIR shares the horizontal pass of two adjacent columns:
+// lane 2j filters columns (2j, 2j+1) of the first row, lane 2j+1 the same columns of the second row.  Each lane reads
+// the 12 columns 2j .. 2j+11 once (12 ds_read_b128 for two output pixels instead of 22) and runs the same 44 packed
+// FMAs and two SSIM formulas a lane of k_ssim_gauss runs for its two rows.  The vertical pass is unchanged (one
+// column per thread, rolling 11-slot accumulators).  LDS rows are QT + 1 float4 apart, so the two lanes of a pair sit
+// in different bank groups and every ds_read_b128 stays conflict-free.
+// ---------------------------------------------------------------------------
+template <int QT>
+__global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dist,
+                                                      int64_t ref_fs, int64_t dist_fs, plane_group g, int64_t row_stride,
+                                                      int step, int w, int h, int ncb, int nstrips, int QS,
+                                                      double *__restrict__ partials, int64_t partial_plane_stride,
+                                                      int n_planes, vqa_plane_metrics *__restrict__ res)
+{
+    constexpr int QOUT = QT - 10;
+    __shared__ float4 vb[2][2][QT + 1]; // [step parity][row of the pair][column]
+    __shared__ double red[4];
+    __shared__ unsigned long long redu[4];
+    const int f = blockIdx.y;
+    const int t = threadIdx.x;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int ch = seq % g.count, tile = (seq / g.count) * 8 + xcd;
+    const int bpp = ncb * nstrips;
+    if (tile >= bpp) return;
+    const int cb = tile % ncb, sb = tile / ncb;
+    const int xs = cb * QOUT, ys = sb * QS;
+    const int xin = xs + t;
+    const int ow = w - 10;
+    const int nrows = min(QS + 10, h - ys);
+    const bool last_cb = cb == ncb - 1, last_sb = sb == nstrips - 1;
+    const bool in_c = xin < w;
+    const bool own_c = in_c && (last_cb || t < QOUT);
+    // horizontal role: columns hc, hc + 1 of row (t & 1) of the step's pair
+    const int hc = t & ~1, hrow = t & 1;
+    const bool out_a = hc < QOUT && xs + hc < ow, out_b = hc + 1 < QOUT && xs + hc + 1 < ow;
+    const int64_t base = g.offset[ch] + (int64_t)ys * row_stride;
+    const uint8_t *rbase = ref + (int64_t)f * ref_fs + base;
+    const uint8_t *dbase = dist + (int64_t)f * dist_fs + base;
+    const uint32_t coff = (uint32_t)((in_c ? xin : 0) * step);
+
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc[11];
+#pragma unroll
+    for (int s = 0; s < 11; s++) acc[s] = f4{0.f, 0.f, 0.f, 0.f};
+    float ssim_acc = 0.f;
+    uint32_t sse_acc = 0;
+    float sse_sq = 0.f, sse_xy = 0.f;
+    float own_f = own_c ? 1.f : 0.f;
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void *)rbase, (short)0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc((void *)dbase, (short)0, -1, 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t &rs, int rr) -> uint32_t {
+        return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, coff, (int)((int64_t)rr * row_stride), 0);
+    };
+    uint32_t nr = ld(rres, 0), nd = ld(dres, 0);
+
+    // LDS double buffering: a step stores into the buffer the step BEFORE LAST read from, and the one barrier per step
+    // orders that.  A 22-row group has 11 steps - an odd number - so the buffer of step st is (st & 1) ^ (group parity):
+    // gpar flips per group (the first version used st & 1 alone: the last step of a group and the first step of the
+    // next then shared a buffer with no barrier between read and overwrite - a race that every parity test survived
+    // and that the bench's serial-vs-timed comparison caught; tests/test_gpu_parity.py now repeats a batch 40 times).
+    int gpar = 0;
+    // vertical pass of one input row (as k_ssim_gauss); emit: store the completed output row into vb[sp][slot][t]
+    auto vrow = [&](const int p, const int r, const bool emit, const int sp, const int slot) {
+        const uint32_t cr = nr, cd = nd;
+        {
+            const int rr = min(r + 1, nrows - 1);
+            nr = ld(rres, rr);
+            nd = ld(dres, rr);
+        }
+        const f2 xy = f2{__uint_as_float(0x4B000000u | cr), __uint_as_float(0x4B000000u | cd)} - f2{8388736.f, 8388736.f};
+        f2 v1 = xy.xx * xy;
+        v1.x = fmaf(xy.y, xy.y, v1.x);
+        sse_sq = fmaf(own_f, v1.x, sse_sq);
+        sse_xy = fmaf(own_f, v1.y, sse_xy);
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const int s = (p - k + 11) % 11;
+            if (k == 0) {
+                acc[s].xy = gw(0) * xy;
+                acc[s].zw = gw(0) * v1;
+            } else {
+                acc[s].xy = __builtin_elementwise_fma(f2{gw(k), gw(k)}, xy, acc[s].xy);
+                acc[s].zw = __builtin_elementwise_fma(f2{gw(k), gw(k)}, v1, acc[s].zw);
+            }
+        }
+        if (emit) *(f4 *)&vb[sp][slot][t] = acc[(p + 1) % 11];
+    };
+    // horizontal pass + SSIM of the step's two output rows: this lane's row is hrow (rows_out = 1: only row 0 exists)
+    auto hpass = [&](const int sp, const int rows_out) {
+        __syncthreads();
+        if (out_a && hrow < rows_out) {
+            const float4 *src = &vb[sp][hrow][hc];
+            f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, b0 = {0.f, 0.f}, b1 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const float4 q = src[i];
+                if (i < 11) {
+                    a0 = __builtin_elementwise_fma(f2{gw(i), gw(i)}, f2{q.x, q.y}, a0);
+                    a1 = __builtin_elementwise_fma(f2{gw(i), gw(i)}, f2{q.z, q.w}, a1);
+                }
+                if (i > 0) {
+                    b0 = __builtin_elementwise_fma(f2{gw(i - 1), gw(i - 1)}, f2{q.x, q.y}, b0);
+                    b1 = __builtin_elementwise_fma(f2{gw(i - 1), gw(i - 1)}, f2{q.z, q.w}, b1);
+                }
+            }
+            const float sb_ = ssim_centered(b0, b1);
+            ssim_acc += ssim_centered(a0, a1) + (out_b ? sb_ : 0.f);
+        }
+    };
+
+    // 22 rows (two turns of the accumulator ring, 11 steps of two rows) per iteration; QS is a multiple of 22, so a
+    // strip's owned rows are its full iterations and the rest (10 halo rows, or the last strip's leftover) goes through
+    // one guarded copy below.
+    const int nfull = nrows / 22;
+    int flush = 0;
+    for (int gI = 0; gI < nfull; gI++) {
+        const int r0 = gI * 22;
+        if (++flush == 11) { sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy); sse_sq = sse_xy = 0.f; flush = 0; } // 242 rows
+#pragma unroll
+        for (int st = 0; st < 11; st++) {
+            const bool emit = st >= 5 || gI > 0; // rows 0..9 of a strip complete no output row
+            vrow((2 * st) % 11, r0 + 2 * st, emit, (st & 1) ^ gpar, 0);
+            vrow((2 * st + 1) % 11, r0 + 2 * st + 1, emit, (st & 1) ^ gpar, 1);
+            if (emit) hpass((st & 1) ^ gpar, 2);
+        }
+        gpar ^= 1;
+    }
+    sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy);
+    sse_sq = sse_xy = 0.f;
+    if (!last_sb) own_f = 0.f; // the halo rows belong to the next strip
+    {
+        const int r0 = nfull * 22;
+#pragma unroll
+        for (int st = 0; st < 11; st++) {
+            const int ra = r0 + 2 * st;
+            if (ra < nrows) {
+                const bool emit = ra >= 10, has_b = ra + 1 < nrows;
+                vrow((2 * st) % 11, ra, emit, (st & 1) ^ gpar, 0);
+                if (has_b) vrow((2 * st + 1) % 11, ra + 1, emit, (st & 1) ^ gpar, 1);
+                if (emit) hpass((st & 1) ^ gpar, has_b ? 2 : 1);
             }
         }
     }
+    sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy);
     const double bs = block_sum((double)ssim_acc, red);
     const unsigned long long be = block_sum_u64((unsigned long long)sse_acc, redu);
     if (t == 0) {
@@ -241,16 +439,12 @@ __global__ void k_ssim_finalize(const double *__restrict__ partials, int bpp, in
     res[(int64_t)f * n_planes + plane_index].ssim = s * inv_count;
 }
 
-// A/B knob for tuning runs (VQA_SSIM_VARIANT): {threads, pixel prefetch rows, LDS reads in flight}:
-// 0 = {256,2,compiler's}, 1 = {256,2,11}, 2 = {256,2,6}, 3 = {256,2,4}, 4 = {128,2,compiler's}, 5 = {256,1,compiler's}
+// Shipped: k_ssim_gauss_p2<256>.  Lab build only (-DVQA_AB_VARIANTS, VQA_SSIM_VARIANT): the one-row-per-barrier kernel
+// k_ssim_gauss<threads, -, LDS reads in flight>: 1 = {256,11}, 2 = {256,6}, 3 = {256,4}, 4 = {128,compiler's},
+// 5 = {256,compiler's} (round 3's shipped configuration)
 static int ssim_variant()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("VQA_SSIM_VARIANT");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 5) v = 0;
-    }
+    static const int v = [] { const int e = ab_knob("VQA_SSIM_VARIANT", 0); return (e < 0 || e > 5) ? 0 : e; }();
     return v;
 }
 static int ssim_qout() { return (ssim_variant() == 4 ? 128 : 256) - 10; }
@@ -279,17 +473,25 @@ void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dis
     plane_group g;
     g.count = count;
     for (int i = 0; i < 4; i++) { g.offset[i] = planes[idx[i < count ? i : 0]].offset; g.plane_index[i] = idx[i < count ? i : 0]; }
+#ifdef VQA_AB_VARIANTS
 #define LAUNCH_SSIM(NT, PF, HPF)                                                                                      \
     hipLaunchKernelGGL((k_ssim_gauss<NT, PF, HPF>), dim3((bpp + 7) / 8 * 8 * count, n), dim3(NT), 0, st, ref, dist, ref_frame_stride,\
                        dist_frame_stride, g, pd.row_stride, pd.pixel_step, w, h, ncb, ns, QS, partials,               \
                        partial_plane_stride, n_planes, res)
+#endif
     switch (ssim_variant()) {
+#ifdef VQA_AB_VARIANTS
     case 1: LAUNCH_SSIM(256, 2, 11); break;
     case 2: LAUNCH_SSIM(256, 2, 6); break;
     case 3: LAUNCH_SSIM(256, 2, 4); break;
     case 4: LAUNCH_SSIM(128, 2, 0); break;
-    case 5: LAUNCH_SSIM(256, 1, 0); break;
-    default: LAUNCH_SSIM(256, 2, 0); break;
+    case 5: LAUNCH_SSIM(256, 2, 0); break; // round 3's shipped kernel (one row per barrier), with round 4's loop structure
+#endif
+    default: // the shipped kernel: two rows per barrier, lane pairs share the horizontal pass
+        hipLaunchKernelGGL((k_ssim_gauss_p2<256>), dim3((bpp + 7) / 8 * 8 * count, n), dim3(256), 0, st, ref, dist, ref_frame_stride,
+                           dist_frame_stride, g, pd.row_stride, pd.pixel_step, w, h, ncb, ns, QS, partials,
+                           partial_plane_stride, n_planes, res);
+        break;
     }
 #undef LAUNCH_SSIM
     for (int i = 0; i < count; i++)

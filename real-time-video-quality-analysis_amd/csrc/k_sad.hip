@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void k_block_sad(const uint8_t *__restrict__ p
     }
 }
 
+#ifdef VQA_AB_VARIANTS // lab build only
 // ---------------------------------------------------------------------------
 // Pruned form (VQA_SAD_VARIANT=2; NOT the default): the same winner, found without evaluating most candidates.
 // Measured on MI355X, 256 x 1080p (round 2): S-natural 1.59-1.65 ms, S-noise 3.5 ms, against 1.29 ms for the exhaustive
@@ -472,6 +473,8 @@ __global__ __launch_bounds__(256) void k_block_sad_sea(const uint8_t *__restrict
     }
 }
 
+#endif // VQA_AB_VARIANTS
+
 void launch_block_sad(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
                       int range, bool first_has_prev, vqa_frame_metrics *res)
 {
@@ -480,17 +483,16 @@ void launch_block_sad(hipStream_t st, const uint8_t *planes, int pitch, int64_t 
     const int tasks = nby * ((nbx + 3) / 4);
     int bpf = (tasks + 4 * 4 - 1) / (4 * 4); // ~4 tasks per wave
     bpf = bpf < 1 ? 1 : (bpf > 256 ? 256 : bpf);
-    static int variant = -1; // A/B knob (VQA_SAD_VARIANT): 0 = exhaustive search (default), 2 = pruned search
-    if (variant < 0) {
-        const char *e = getenv("VQA_SAD_VARIANT");
-        variant = (e && atoi(e) == 2) ? 2 : 0;
-    }
-    if (variant == 0)
-        hipLaunchKernelGGL(k_block_sad, dim3((unsigned)(8 * (((long long)bpf * n + 7) / 8))), dim3(256), 0, st, planes, pitch,
-                           plane_stride, h, w, range, (int)first_has_prev, res, bpf, bpf * n);
-    else
+#ifdef VQA_AB_VARIANTS
+    static const int variant = ab_knob("VQA_SAD_VARIANT", 0) == 2 ? 2 : 0; // 0 = exhaustive search (shipped), 2 = pruned search
+    if (variant == 2) {
         hipLaunchKernelGGL(k_block_sad_sea, dim3(bpf, n), dim3(256), 0, st, planes, pitch, plane_stride, h, w, range,
                            (int)first_has_prev, res);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(k_block_sad, dim3((unsigned)(8 * (((long long)bpf * n + 7) / 8))), dim3(256), 0, st, planes, pitch,
+                       plane_stride, h, w, range, (int)first_has_prev, res, bpf, bpf * n);
 }
 
 } // namespace vqa

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -37,9 +38,15 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 struct vqa_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipStream_t side[2] = {nullptr, nullptr};   // VQA_OVERLAP=1: block-SAD and the Canny chain on their own streams
+    hipStream_t side[2] = {nullptr, nullptr};   // VQA_OPT_OVERLAP: block-SAD and the Canny chain on their own streams
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::string last_err;
+    // options (vqa_set_option)
+    bool opt_overlap = true, opt_hyst_stats = false;
+    // -DVQA_TEST_SEAMS only (lab build; read from the environment once, in vqa_create)
+    int seam_hyst_max_rounds = 0;   // VQA_HYST_MAX_ROUNDS: the hysteresis tail's round bound (0 = the shipped bound)
+    long seam_fail_at = 0;          // VQA_FAIL_ENSURE_AT=N: the N-th scratch reservation of this ctx reports VQA_ERR_OOM
+    long seam_ensure_calls = 0;
 
     // device scratch (grow-only)
     dbuf gray_full, planeA, planeB, state, res_dev, partials, tile_flags, dirty0, dirty1, again_dev;
@@ -109,6 +116,13 @@ void prof_collect(vqa_ctx *c)
     }
     c->ev_open.clear();
 }
+
+// a failed submit: its event pairs go back to the pool unread
+void prof_discard(vqa_ctx *c)
+{
+    for (auto &t : c->ev_open) { c->ev_pool.push_back(std::get<1>(t)); c->ev_pool.push_back(std::get<2>(t)); }
+    c->ev_open.clear();
+}
 } // namespace
 
 #define HIPCHK(ctx, call)                                                                                  \
@@ -122,11 +136,26 @@ void prof_collect(vqa_ctx *c)
         }                                                                                                  \
     } while (0)
 
+// every stream this ctx may have work on (the main one and, once created, the two side streams of VQA_OPT_OVERLAP)
+static int sync_all(vqa_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; i++)
+        if (c->side[i]) HIPCHK(c, hipStreamSynchronize(c->side[i]));
+    return VQA_OK;
+}
+
 static int ensure(vqa_ctx *c, dbuf &b, size_t bytes)
 {
+#ifdef VQA_TEST_SEAMS
+    if (c->seam_fail_at > 0 && ++c->seam_ensure_calls == c->seam_fail_at) {
+        c->last_err = "test seam: scratch reservation #" + std::to_string(c->seam_fail_at) + " made to fail";
+        return VQA_ERR_OOM;
+    }
+#endif
     if (bytes <= b.cap) return VQA_OK;
-    // contents are scratch; a pending async user would be on our own stream
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // contents are scratch; a pending async user is on one of our own streams
+    if (int rc = sync_all(c)) return rc;
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     const size_t want = bytes + bytes / 8 + 256;
@@ -138,7 +167,7 @@ static int ensure(vqa_ctx *c, dbuf &b, size_t bytes)
 static int ensure_pinned(vqa_ctx *c, void *&p, size_t &cap, size_t bytes)
 {
     if (bytes <= cap) return VQA_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = sync_all(c)) return rc;
     if (p) HIPCHK(c, hipHostFree(p));
     p = nullptr; cap = 0;
     HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
@@ -444,15 +473,54 @@ int vqa_create(int device, vqa_ctx **out)
         delete c;
         return VQA_ERR_HIP;
     }
+    // the one environment variable the shipped library reads (documented in vqa.h): the initial VQA_OPT_OVERLAP
+    if (const char *e = getenv("VQA_OVERLAP")) c->opt_overlap = atoi(e) != 0;
+#ifdef VQA_TEST_SEAMS
+    if (const char *e = getenv("VQA_HYST_MAX_ROUNDS")) c->seam_hyst_max_rounds = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = getenv("VQA_FAIL_ENSURE_AT")) c->seam_fail_at = atol(e);
+#endif
     *out = c;
     return VQA_OK;
+}
+
+int vqa_set_option(vqa_ctx *c, int option, int value)
+{
+    if (!c) return VQA_ERR_INVALID;
+    if (c->pend_c || c->pend_q) return VQA_ERR_STATE; // options apply to whole submits
+    switch (option) {
+    case VQA_OPT_OVERLAP: c->opt_overlap = value != 0; return VQA_OK;
+    case VQA_OPT_HYST_STATS: c->opt_hyst_stats = value != 0; return VQA_OK;
+    default: return VQA_ERR_INVALID;
+    }
+}
+
+int vqa_get_option(const vqa_ctx *c, int option, int *value)
+{
+    if (!c || !value) return VQA_ERR_INVALID;
+    switch (option) {
+    case VQA_OPT_OVERLAP: *value = c->opt_overlap ? 1 : 0; return VQA_OK;
+    case VQA_OPT_HYST_STATS: *value = c->opt_hyst_stats ? 1 : 0; return VQA_OK;
+    default: return VQA_ERR_INVALID;
+    }
+}
+
+int vqa_build_flavour(void)
+{
+    int f = 0;
+#ifdef VQA_AB_VARIANTS
+    f |= 1;
+#endif
+#ifdef VQA_TEST_SEAMS
+    f |= 2;
+#endif
+    return f;
 }
 
 int vqa_destroy(vqa_ctx *c)
 {
     if (!c) return VQA_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     dbuf *bufs[] = {&c->gray_full, &c->planeA, &c->planeB, &c->state, &c->res_dev, &c->partials, &c->tile_flags,
                     &c->dirty0, &c->dirty1, &c->again_dev, &c->stage_frames, &c->stage_prev, &c->dct_scratch,
                     &c->dct_pe, &c->dct_pt, &c->qres_dev, &c->qpartials, &c->qstage_ref, &c->qstage_dist,
@@ -527,8 +595,7 @@ int vqa_copy_d2h(vqa_ctx *c, void *dst, const void *src, size_t bytes)
 int vqa_sync(vqa_ctx *c)
 {
     if (!c) return VQA_ERR_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return VQA_OK;
+    return sync_all(c);
 }
 void *vqa_stream(vqa_ctx *c) { return c ? (void *)c->stream : nullptr; }
 // internal accessors for vqa_comm.hip (not part of the ABI: hidden visibility)
@@ -536,8 +603,26 @@ extern "C" __attribute__((visibility("hidden"))) int vqa_ctx_device_(const vqa_c
 extern "C" __attribute__((visibility("hidden"))) void *vqa_ctx_stream_(const vqa_ctx *c) { return (void *)c->stream; }
 
 // ---------------------------------------------------------------------------
-int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev0, int mem_kind, int n, int h, int w,
-                          int64_t frame_stride, int64_t row_stride, uint32_t mask, const vqa_params *params)
+// A submit that fails after it has started to enqueue must not hand the caller's buffers (and this ctx's scratch) back
+// while kernels or copies still use them: whatever the failing step was - a reservation, a copy, a launch, in the first
+// slice or a later one, before or after the fork onto the side streams - the public entry points below drain EVERY
+// stream of the ctx, drop the submit's timing events and leave the ctx idle and usable (pend_* stay 0).  The reference's
+// convention for a failed step is log-and-re-raise with nothing left running (video_processing.py:295-297).
+static int drain_failed_submit(vqa_ctx *c, int rc, bool touched)
+{
+    if (rc != VQA_OK && touched) {
+        const std::string why = c->last_err; // keep the first error's text
+        (void)sync_all(c);
+        (void)hipGetLastError();
+        prof_discard(c);
+        c->last_err = why;
+    }
+    return rc;
+}
+
+static int complexity_submit_body(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev0, int mem_kind, int n, int h, int w,
+                                  int64_t frame_stride, int64_t row_stride, uint32_t mask, const vqa_params *params,
+                                  bool &touched)
 {
     if (!c || !frames || n <= 0 || h <= 0 || w <= 0) return VQA_ERR_INVALID;
     if (mem_kind != VQA_MEM_HOST && mem_kind != VQA_MEM_DEVICE) return VQA_ERR_INVALID;
@@ -555,6 +640,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     if ((int64_t)h * w > (1ll << 28)) return VQA_ERR_UNSUPPORTED;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    touched = true; // from here on a failure is drained by the caller (drain_failed_submit)
 
     const int rw = P.resize_w ? P.resize_w : w, rh = P.resize_h ? P.resize_h : h;
     const bool resized = !(rw == w && rh == h);
@@ -613,8 +699,6 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
 
     // Frames ride in gridDim.y (<= 65535): larger batches are enqueued as consecutive slices on the same stream.  A
     // slice's "previous frame" is the last frame of the slice before it; scratch planes are reused (stream order).
-    // A slice that fails after earlier slices were enqueued must not hand the buffers back while their kernels are in
-    // flight (pend_c stays 0, so the caller could resubmit or free them): the loop drains the stream before it returns.
     const int SLICE = 32768;
     auto run_slice = [&](const int a0) -> int {
     const int n = n_all - a0 < SLICE ? n_all - a0 : SLICE;
@@ -691,10 +775,10 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         }
     }
 
-    // ---- VQA_OVERLAP=1 (experiment): block-SAD, the Canny chain and DCT/ORB only share the gray planes as input, so
-    // they may run side by side: SAD and Canny fork onto their own streams here and join before the results are copied
-    static int overlap = -1;
-    if (overlap < 0) { const char *e = getenv("VQA_OVERLAP"); overlap = (e && atoi(e) > 0) ? 1 : 0; }
+    // ---- VQA_OPT_OVERLAP (default on): block-SAD, the Canny chain and DCT/ORB only share the gray planes as input, so
+    // they run side by side: SAD and Canny fork onto their own streams here and join before the results are copied
+    // (QSAD-bound, scalar-bound and latency-bound kernels next to each other: +3 % on the full suite, LAB_NOTES.md)
+    const bool overlap = c->opt_overlap && ((want_m && P.motion_mode == VQA_MOTION_SAD) || want_e);
     hipStream_t st_sad = st, st_canny = st;
     if (overlap) {
         for (int i = 0; i < 2; i++) {
@@ -756,7 +840,7 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
         int round = 0;
         {
             prof_scope ps_(c, VQA_K_CANNY_HYST, st_canny);
-            launch_canny_hyst_all(st_canny, strong, weak, n, ph, pw, queued[1], lists[1], cnt(1), res);
+            launch_canny_hyst_all(st_canny, strong, weak, n, ph, pw, queued[1], lists[1], cnt(1), res, c->opt_hyst_stats);
         }
         {
             // rounds 1..WIDE (still many tiles): wide grid over the per-frame lists; then the tail kernel
@@ -765,10 +849,14 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
             // (a frame's tail runs on ONE workgroup: big frames in small batches get more wide rounds first)
             const canny_geom cg = canny_tiles(ph, pw);
             int WIDE = (cg.tiles_x * cg.tiles_y > 1024 && n < 256) ? 8 : 6; // (measured: 1080p x 256: 4 -> 0.40 ms, 6 -> 0.38 ms of hysteresis)
-            if (const char *e = getenv("VQA_HYST_WIDE")) WIDE = atoi(e) > 0 ? atoi(e) : WIDE; // tuning knob
+#ifdef VQA_AB_VARIANTS
+            { static const int e = ab_knob("VQA_HYST_WIDE", 0); if (e > 0) WIDE = e; } // lab build: tuning knob
+#endif
             for (round = 1; round <= WIDE; round++) {
                 const int in = round & 1, out = in ^ 1;
-                if (getenv("VQA_HYST_TRACE")) { // debugging aid: tiles queued for this round, summed over frames (synchronises)
+#ifdef VQA_AB_VARIANTS
+                static const bool trace = ab_knob("VQA_HYST_TRACE", 0) != 0;
+                if (trace) { // lab build, debugging aid: tiles queued for this round, summed over frames (synchronises)
                     std::vector<uint32_t> hc((size_t)n * NS);
                     (void)hipStreamSynchronize(st_canny);
                     (void)hipMemcpy(hc.data(), cnt(round), sizeof(uint32_t) * hc.size(), hipMemcpyDeviceToHost);
@@ -776,15 +864,16 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
                     for (uint32_t v : hc) tot += v;
                     fprintf(stderr, "[hyst] round %d: %llu of %u tiles queued\n", round, tot, ntiles);
                 }
+#endif
                 launch_canny_hyst_list(st_canny, strong, weak, n, ph, pw, queued[in], lists[in], cnt(round), queued[out], lists[out],
-                                       cnt(round + 1), cnt(round + 2), res);
+                                       cnt(round + 1), cnt(round + 2), res, c->opt_hyst_stats);
             }
             // the tail alternates between the counter the last wide round appended to and the one it zeroed
             unsigned *tc[2];
             tc[round & 1] = cnt(round);
             tc[(round & 1) ^ 1] = cnt(round + 1);
             launch_canny_hyst_tail(st_canny, strong, weak, n, ph, pw, lists[0], tc[0], queued[0], lists[1], tc[1], queued[1],
-                                   round & 1, res);
+                                   round & 1, res, c->opt_hyst_stats, c->seam_hyst_max_rounds);
         }
         launch_canny_finish(st_canny, strong, n, ph, pw, res);
         c->last_has_state = true;
@@ -807,13 +896,8 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     c->last_n = n; c->last_has_full = need_full; c->last_has_planes = need_planes; // (debug planes show the last slice)
     return VQA_OK;
     }; // run_slice
-    for (int a0 = 0; a0 < n_all; a0 += SLICE) {
-        const int src = run_slice(a0);
-        if (src) {
-            if (a0 > 0) (void)hipStreamSynchronize(st);
-            return src;
-        }
-    }
+    for (int a0 = 0; a0 < n_all; a0 += SLICE)
+        if (const int src = run_slice(a0)) return src; // (the caller drains)
     const bool has_prev0 = batch_has_prev0;
 
     HIPCHK(c, hipGetLastError());
@@ -834,6 +918,14 @@ int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev
     return VQA_OK;
 }
 
+int vqa_complexity_submit(vqa_ctx *c, const uint8_t *frames, const uint8_t *prev0, int mem_kind, int n, int h, int w,
+                          int64_t frame_stride, int64_t row_stride, uint32_t mask, const vqa_params *params)
+{
+    bool touched = false;
+    const int rc = complexity_submit_body(c, frames, prev0, mem_kind, n, h, w, frame_stride, row_stride, mask, params, touched);
+    return drain_failed_submit(c, rc, touched);
+}
+
 int vqa_complexity_wait(vqa_ctx *c, vqa_frame_metrics *out, int n)
 {
     if (!c || !out) return VQA_ERR_INVALID;
@@ -850,8 +942,8 @@ int vqa_complexity_wait(vqa_ctx *c, vqa_frame_metrics *out, int n)
 }
 
 // ---------------------------------------------------------------------------
-int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int mem_kind, int n, int64_t ref_fs,
-                       int64_t dist_fs, const vqa_plane_desc *planes, int n_planes, int ssim_mode)
+static int quality_submit_body(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int mem_kind, int n, int64_t ref_fs,
+                               int64_t dist_fs, const vqa_plane_desc *planes, int n_planes, int ssim_mode, bool &touched)
 {
     if (!c || !ref || !dist || n <= 0 || !planes || n_planes <= 0 || n_planes > 4) return VQA_ERR_INVALID;
     if (mem_kind != VQA_MEM_HOST && mem_kind != VQA_MEM_DEVICE) return VQA_ERR_INVALID;
@@ -878,6 +970,7 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
     if (n > 1 && (ref_fs < span || dist_fs < span)) return VQA_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    touched = true;
     const uint8_t *dref = ref, *ddist = dist;
     if (mem_kind == VQA_MEM_HOST) {
         const size_t rs = (size_t)(n - 1) * ref_fs + span, ds = (size_t)(n - 1) * dist_fs + span;
@@ -930,6 +1023,14 @@ int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int 
     HIPCHK(c, hipMemcpyAsync(c->qres_host, c->qres_dev.p, sizeof(vqa_plane_metrics) * nent, hipMemcpyDeviceToHost, st));
     c->pend_q = (int)nent;
     return VQA_OK;
+}
+
+int vqa_quality_submit(vqa_ctx *c, const uint8_t *ref, const uint8_t *dist, int mem_kind, int n, int64_t ref_fs,
+                       int64_t dist_fs, const vqa_plane_desc *planes, int n_planes, int ssim_mode)
+{
+    bool touched = false;
+    const int rc = quality_submit_body(c, ref, dist, mem_kind, n, ref_fs, dist_fs, planes, n_planes, ssim_mode, touched);
+    return drain_failed_submit(c, rc, touched);
 }
 
 int vqa_quality_wait(vqa_ctx *c, vqa_plane_metrics *out, int n_entries)

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,22 +35,28 @@ struct rccl_api {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    bool fake = false; // lab build: the stand-in was selected when the table was built (latched)
 };
 
-// ---- test seam (VQA_COMM_FAKE_RCCL=1): an in-library stand-in for the seven RCCL entry points, so that the
+#ifdef VQA_TEST_SEAMS
+// ---- test seam, lab build only (VQA_COMM_FAKE_RCCL=1): an in-library stand-in for the seven RCCL entry points, so that the
 // SINGLE-PROCESS MULTI-CONTEXT path (device list, one scratch buffer per context on its own device, staging copies,
 // group start/end bracketing, row layout of vals) can be exercised on a box with one GPU, where RCCL itself refuses
 // two ranks on one device.  The fake checks the bracketing, sums on the host, and records every call in a trace
-// (vqa_comm_debug_trace).  It is never selected unless the environment variable is set.
+// (vqa_comm_debug_trace).  It is never selected unless the environment variable is set when the table is built, and
+// the decision is LATCHED with the table (rccl_api::fake): the mode cannot flip once real RCCL has been loaded.  The
+// stand-in's globals sit behind one mutex (the table itself was already thread-safe).
 struct fake_comm { int rank, nranks, dev; };
 struct fake_pending { const void *send; void *recv; size_t count; fake_comm *comm; hipStream_t st; };
+static std::mutex g_fake_mu;
 static std::vector<fake_pending> g_fake_pending;
 static bool g_fake_in_group = false;
 static std::string g_fake_trace;
 
-static ncclResult_t fake_GetUniqueId(ncclUniqueId *u) { memset(u, 0x5a, sizeof *u); g_fake_trace += "GetUniqueId;"; return ncclSuccess; }
+static ncclResult_t fake_GetUniqueId(ncclUniqueId *u) { std::lock_guard<std::mutex> lk(g_fake_mu); memset(u, 0x5a, sizeof *u); g_fake_trace += "GetUniqueId;"; return ncclSuccess; }
 static ncclResult_t fake_CommInitAll(ncclComm_t *comms, int n, const int *devs)
 {
+    std::lock_guard<std::mutex> lk(g_fake_mu);
     g_fake_trace += "CommInitAll(n=" + std::to_string(n) + ",devs=";
     for (int i = 0; i < n; i++) {
         comms[i] = (ncclComm_t) new fake_comm{i, n, devs[i]};
@@ -60,14 +67,16 @@ static ncclResult_t fake_CommInitAll(ncclComm_t *comms, int n, const int *devs)
 }
 static ncclResult_t fake_CommInitRank(ncclComm_t *comm, int n, ncclUniqueId, int rank)
 {
+    std::lock_guard<std::mutex> lk(g_fake_mu);
     if (n != 1) return ncclInvalidUsage; // the fake has no second process to meet
     *comm = (ncclComm_t) new fake_comm{rank, n, -1};
     g_fake_trace += "CommInitRank(n=1);";
     return ncclSuccess;
 }
-static ncclResult_t fake_CommDestroy(ncclComm_t c) { delete (fake_comm *)c; g_fake_trace += "CommDestroy;"; return ncclSuccess; }
+static ncclResult_t fake_CommDestroy(ncclComm_t c) { std::lock_guard<std::mutex> lk(g_fake_mu); delete (fake_comm *)c; g_fake_trace += "CommDestroy;"; return ncclSuccess; }
 static ncclResult_t fake_GroupStart()
 {
+    std::lock_guard<std::mutex> lk(g_fake_mu);
     if (g_fake_in_group) return ncclInvalidUsage;
     g_fake_in_group = true;
     g_fake_pending.clear();
@@ -77,6 +86,7 @@ static ncclResult_t fake_GroupStart()
 static ncclResult_t fake_AllReduce(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm,
                                    hipStream_t st)
 {
+    std::lock_guard<std::mutex> lk(g_fake_mu);
     if (!g_fake_in_group || dt != ncclFloat64 || op != ncclSum) return ncclInvalidUsage; // must sit inside a group
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, recv) != hipSuccess) return ncclInvalidArgument;
@@ -88,6 +98,7 @@ static ncclResult_t fake_AllReduce(const void *send, void *recv, size_t count, n
 }
 static ncclResult_t fake_GroupEnd()
 {
+    std::lock_guard<std::mutex> lk(g_fake_mu);
     if (!g_fake_in_group) return ncclInvalidUsage;
     g_fake_in_group = false;
     g_fake_trace += "GroupEnd(" + std::to_string(g_fake_pending.size()) + ");";
@@ -95,22 +106,29 @@ static ncclResult_t fake_GroupEnd()
     if ((int)g_fake_pending.size() != g_fake_pending[0].comm->nranks) return ncclInvalidUsage; // every rank must take part
     const size_t count = g_fake_pending[0].count;
     std::vector<double> sum(count, 0.0), tmp(count);
+    int dev0 = 0;
+    (void)hipGetDevice(&dev0);
     for (auto &p : g_fake_pending) {
+        if (p.comm->dev >= 0) (void)hipSetDevice(p.comm->dev); // (each context's buffer lives on its own device)
         if (p.count != count || hipStreamSynchronize(p.st) != hipSuccess) return ncclInvalidUsage;
         if (hipMemcpy(tmp.data(), p.send, sizeof(double) * count, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
         for (size_t i = 0; i < count; i++) sum[i] += tmp[i];
     }
-    for (auto &p : g_fake_pending)
+    for (auto &p : g_fake_pending) {
+        if (p.comm->dev >= 0) (void)hipSetDevice(p.comm->dev);
         if (hipMemcpy(p.recv, sum.data(), sizeof(double) * count, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    }
+    (void)hipSetDevice(dev0);
     return ncclSuccess;
 }
 static const char *fake_GetErrorString(ncclResult_t r) { return r == ncclSuccess ? "ok" : "fake rccl: invalid usage"; }
 
-static bool fake_mode()
+static bool fake_env()
 {
     const char *e = getenv("VQA_COMM_FAKE_RCCL");
     return e && e[0] == '1';
 }
+#endif // VQA_TEST_SEAMS
 
 // Thread-safe by construction: a function-local static initialised once by the lambda (C++11 magic statics), so two
 // host threads creating communicators at the same time can never see a half-filled table.
@@ -118,13 +136,15 @@ rccl_api &rccl()
 {
     static rccl_api a = [] {
         rccl_api t;
-        if (fake_mode()) {
+#ifdef VQA_TEST_SEAMS
+        if (fake_env()) {
             t.GetUniqueId = fake_GetUniqueId; t.CommInitAll = fake_CommInitAll; t.CommInitRank = fake_CommInitRank;
             t.CommDestroy = fake_CommDestroy; t.AllReduce = fake_AllReduce; t.GroupStart = fake_GroupStart;
             t.GroupEnd = fake_GroupEnd; t.GetErrorString = fake_GetErrorString;
-            t.ok = true;
+            t.ok = t.fake = true;
             return t;
         }
+#endif
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
             t.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -191,7 +211,7 @@ int vqa_comm_create(vqa_ctx *const *ctxs, int n_ctx, vqa_comm **out)
     for (int i = 0; i < n_ctx; i++) {
         if (!ctxs[i]) return VQA_ERR_INVALID;
         for (int j = 0; j < i; j++) // one ctx per device (the test seam alone may put two on one: it never calls RCCL)
-            if (vqa_ctx_device_(ctxs[i]) == vqa_ctx_device_(ctxs[j]) && !fake_mode()) {
+            if (vqa_ctx_device_(ctxs[i]) == vqa_ctx_device_(ctxs[j]) && !rccl().fake) {
                 g_create_err = "vqa_comm_create: two contexts on device " + std::to_string(vqa_ctx_device_(ctxs[i]));
                 return VQA_ERR_INVALID;
             }
@@ -267,7 +287,14 @@ int vqa_comm_size(const vqa_comm *c) { return c ? c->nranks : VQA_ERR_INVALID; }
 const char *vqa_comm_last_error(const vqa_comm *c) { return c ? c->last_err.c_str() : g_create_err.c_str(); }
 
 // the calls the test seam received, in order ("" unless VQA_COMM_FAKE_RCCL=1)
-const char *vqa_comm_debug_trace(void) { return g_fake_trace.c_str(); }
+const char *vqa_comm_debug_trace(void)
+{
+#ifdef VQA_TEST_SEAMS
+    return g_fake_trace.c_str();
+#else
+    return ""; // the shipped library has no stand-in
+#endif
+}
 
 // vals: [local contexts][count] doubles, row i belongs to the i-th local context; in place.
 int vqa_allreduce(vqa_comm *c, double *vals, int count)

@@ -5,7 +5,29 @@
 
 #include "../../include/vqa.h"
 
+// Build flavours (csrc/Makefile):
+//   default            the product: one kernel per stage, no environment variable selects an arithmetic path.
+//   -DVQA_AB_VARIANTS  (make lab) additionally compiles the superseded kernels of earlier rounds and their VQA_*_VARIANT /
+//                      tuning selectors, for re-measurement (LAB_NOTES.md); results stay parity-tested.
+//   -DVQA_TEST_SEAMS   (make lab) additionally compiles the fault-injection / stand-in hooks the tests use:
+//                      VQA_COMM_FAKE_RCCL, VQA_HYST_MAX_ROUNDS, VQA_FAIL_ENSURE_AT.
+#ifdef VQA_AB_VARIANTS
+#include <cstdlib>
+#endif
+
 namespace vqa {
+
+// value of an A/B selector: the environment in the lab build, the shipped default otherwise (callers cache it)
+inline int ab_knob(const char *name, int dflt)
+{
+#ifdef VQA_AB_VARIANTS
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // k_gray_hist.hip
 void launch_bgr2gray_hist(hipStream_t st, const uint8_t *bgr, int n, int h, int w, int64_t frame_stride,
@@ -43,15 +65,18 @@ void launch_canny_nms(hipStream_t st, const uint8_t *gray, int pitch, int64_t pl
 // tiles a neighbour enqueued (compact list + dedup flags); *out_count must be 0 at launch.
 unsigned canny_hyst_tiles(int n, int h, int w);
 constexpr int CANNY_HYST_SEGMENTS = 16; // work-list segments per frame (k_canny.hip: HSEG)
+// stats != 0: every tile visit adds its relaxation steps to res[f].hyst_steps (VQA_OPT_HYST_STATS; one atomic per visit)
 void launch_canny_hyst_all(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
-                           int w, unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res);
+                           int w, unsigned *queued, unsigned *out_list, unsigned *out_count, vqa_frame_metrics *res,
+                           int stats);
 void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *in_queued, const unsigned *in_list, const unsigned *in_count,
                             unsigned *out_queued, unsigned *out_list, unsigned *out_count, unsigned *zero_count,
-                            vqa_frame_metrics *res);
+                            vqa_frame_metrics *res, int stats);
 void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *list0, unsigned *cnt0, unsigned *q0, unsigned *list1, unsigned *cnt1,
-                            unsigned *q1, int first_in, vqa_frame_metrics *res);
+                            unsigned *q1, int first_in, vqa_frame_metrics *res, int stats, int max_rounds);
+constexpr int CANNY_HYST_MAX_ROUNDS = 1 << 16; // the tail's drain bound (a 64x64-tile fixpoint over any frame ends far below)
 void launch_canny_finish(hipStream_t st, const unsigned long long *strong, int n, int h, int w, vqa_frame_metrics *res);
 
 // k_sad.hip

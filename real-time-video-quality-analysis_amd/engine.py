@@ -151,6 +151,19 @@ class Engine:
     def sync(self):
         N.check(self.lib.vqa_sync(self.ctx), "vqa_sync", self.ctx)
 
+    # ---- options (include/vqa.h: none of them changes a result) --------------
+    def set_option(self, option, value):
+        N.check(self.lib.vqa_set_option(self.ctx, int(option), int(value)), "vqa_set_option", self.ctx)
+
+    def get_option(self, option):
+        v = C.c_int(0)
+        N.check(self.lib.vqa_get_option(self.ctx, int(option), C.byref(v)), "vqa_get_option", self.ctx)
+        return v.value
+
+    def set_overlap(self, on):
+        """Block-SAD and the Canny chain on side streams inside a complexity submit (default on)."""
+        self.set_option(N.OPT_OVERLAP, 1 if on else 0)
+
     @property
     def stream(self):
         return self.lib.vqa_stream(self.ctx)

@@ -19,10 +19,10 @@ def _ensure_built():
     import shutil
     import subprocess
     csrc = os.path.join(REPO, "real-time-video-quality-analysis_amd", "csrc")
-    if not os.path.exists(os.path.join(csrc, "libvqa_hip.so")):
+    if not (os.path.exists(os.path.join(csrc, "libvqa_hip.so")) and os.path.exists(os.path.join(csrc, "lab", "libvqa_hip_lab.so"))):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         if os.path.exists(hipcc):
-            subprocess.check_call(["make", "-C", csrc, "-j", "8", "HIPCC=" + hipcc])
+            subprocess.check_call(["make", "-C", csrc, "-j", "8", "HIPCC=" + hipcc, "all", "lab"])
     if not os.path.exists(os.path.join(REPO, "oracle", "libvqa_oracle.so")):
         subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle")])
 

@@ -96,6 +96,28 @@ def test_error_paths_without_compute():
             rtvqa_amd.complexity_metrics.process_dct_frame(np.zeros((16, 16, 3), np.uint8), 16, 16)
 
 
+def test_shipped_library_has_no_hidden_switches():
+    """The default library is the product: flavour 0, and the only environment name in its strings is the documented
+    VQA_OVERLAP.  The lab build (superseded kernels, selectors, test seams) is a separate file that nothing loads by default."""
+    import subprocess
+    from rtvqa_amd import _native as N
+    assert os.path.basename(N.LIB_PATH) == "libvqa_hip.so" or os.environ.get("VQA_LIB_PATH")
+    shipped = os.path.join(REPO, "real-time-video-quality-analysis_amd", "csrc", "libvqa_hip.so")
+    names = set(re.findall(r"^VQA_[A-Z0-9_]+$", subprocess.run(["strings", shipped], capture_output=True, text=True).stdout, flags=re.M))
+    assert names == {"VQA_OVERLAP"}, names
+    hdr = open(os.path.join(REPO, "include", "vqa.h")).read()
+    assert "VQA_OVERLAP" in hdr and "VQA_OPT_OVERLAP" in hdr
+    lib = C.CDLL(shipped)
+    assert lib.vqa_build_flavour() == 0
+    lib.vqa_comm_debug_trace.restype = C.c_char_p
+    assert lib.vqa_comm_debug_trace() == b""  # no stand-in in the shipped library
+    lab = C.CDLL(N.LAB_LIB_PATH)
+    assert lab.vqa_build_flavour() == (N.FLAVOUR_AB_VARIANTS | N.FLAVOUR_TEST_SEAMS)
+    lab_names = set(re.findall(r"^VQA_[A-Z0-9_]+$", subprocess.run(["strings", N.LAB_LIB_PATH], capture_output=True, text=True).stdout, flags=re.M))
+    assert {"VQA_COMM_FAKE_RCCL", "VQA_HYST_MAX_ROUNDS", "VQA_FAIL_ENSURE_AT", "VQA_NMS_VARIANT", "VQA_DCT_VARIANT",
+            "VQA_SAD_VARIANT", "VQA_SSIM_VARIANT"} <= lab_names
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(REPO, "real-time-video-quality-analysis_amd")
     for root, _, files in os.walk(pkg):
@@ -213,14 +235,15 @@ print(json.dumps({"vals": list(vals), "size": size, "trace": lib.vqa_comm_debug_
 @pytest.mark.gpu
 def test_multi_context_allreduce_through_the_test_seam():
     """vqa_comm_create with n_ctx > 1 (single process, one context per device: SURVEY 8e's ncclCommInitAll design) has
-    never had two devices to run on.  With VQA_COMM_FAKE_RCCL=1 an in-library stand-in replaces the RCCL entry points, so
+    never had two devices to run on.  In the LAB build, with VQA_COMM_FAKE_RCCL=1, an in-library stand-in replaces the RCCL entry points, so
     everything AROUND them runs on the one GPU of the test box: the device list handed to CommInitAll, one scratch buffer
     per context on its device, the H2D staging of each context's row, group start / one AllReduce per context / group
     end, the D2H of every row.  The stand-in refuses an AllReduce outside a group or a group that lacks a rank."""
     import json
     import subprocess
     import sys
-    env = dict(os.environ, VQA_COMM_FAKE_RCCL="1")
+    from rtvqa_amd import _native as N
+    env = dict(os.environ, VQA_COMM_FAKE_RCCL="1", VQA_LIB_PATH=N.LAB_LIB_PATH)  # the stand-in exists in the lab build only
     out = subprocess.run([sys.executable, "-c", _SEAM_SCRIPT % REPO], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     got = json.loads(out.stdout.strip().splitlines()[-1])

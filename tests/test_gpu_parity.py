@@ -687,7 +687,7 @@ def test_more_than_65535_frames_in_one_submit(engine):
 
 
 def test_pruned_block_sad_variant_is_bit_identical():
-    """VQA_SAD_VARIANT=2 (successive-elimination search, k_block_sad_sea) must return the exhaustive winner: sad_sum
+    """Lab build, VQA_SAD_VARIANT=2 (successive-elimination search, k_block_sad_sea) must return the exhaustive winner: sad_sum
     and the d^2 histogram bit for bit, on natural, noise, ragged and tiny planes and for every search range."""
     import subprocess
     import sys
@@ -706,7 +706,8 @@ def test_pruned_block_sad_variant_is_bit_identical():
         "        assert int(rec[i]['sad_blocks']) == nb and int(rec[i]['sad_sum']) == sad and (rec[i]['mv_d2_hist'] == hist).all(), (kind, h, w, R, i)\n"
         "print('PRUNED-OK')\n" % REPO_ROOT
     )
-    env = dict(os.environ, VQA_SAD_VARIANT="2")
+    from rtvqa_amd import _native as N
+    env = dict(os.environ, VQA_SAD_VARIANT="2", VQA_LIB_PATH=N.LAB_LIB_PATH)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=REPO_ROOT)
     assert r.returncode == 0 and "PRUNED-OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
 
@@ -719,6 +720,8 @@ _VARIANT_CODE = (
     "from oracle import c_oracle as co\n"
     "from oracle import pipeline as pl\n"
     "eng = rtvqa_amd.Engine(0)\n"
+    "assert eng.lib.vqa_build_flavour() == @FLAVOUR@, eng.lib.vqa_build_flavour()\n"
+    "eng.set_option(N.OPT_HYST_STATS, @STATS@)\n"
     "for kind, h, w in (('natural', 270, 480), ('noise', 97, 131), ('natural', 64, 200)):\n"
     "    fr = synth.s_natural(4, h, w, seed=9) if kind == 'natural' else synth.s_noise(4, h, w, seed=9)\n"
     "    rec = eng.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8, canny=(40, 120))\n"
@@ -727,6 +730,7 @@ _VARIANT_CODE = (
     "        e, l1, _ = co.dct8x8(gp, g)\n"
     "        assert abs(rec[i]['dct_energy'] - e) <= 1e-4 * e and abs(rec[i]['temporal_dct_l1'] - l1) <= 1e-4 * l1, ('dct', kind, i)\n"
     "        assert int(rec[i]['edge_count']) == co.canny(g, 40, 120)[0] and not rec[i]['hyst_overflow'], ('canny', kind, i)\n"
+    "        assert (int(rec[i]['hyst_steps']) > 0) == bool(@STATS@), ('hyst_steps', kind, i)\n"
     "        nb, sad, hist = co.block_sad(gp, g, 7)\n"
     "        assert int(rec[i]['sad_sum']) == sad and (rec[i]['mv_d2_hist'] == hist).all(), ('sad', kind, i)\n"
     "    q = eng.quality(fr[:2], fr[1:3], bgr_planes(h, w), N.SSIM_GAUSS)\n"
@@ -739,22 +743,121 @@ _VARIANT_CODE = (
 
 @pytest.mark.parametrize("knob", ["VQA_DCT_VARIANT=4", "VQA_DCT_VARIANT=3", "VQA_DCT_VARIANT=1", "VQA_DCT_LOAD_EARLY=1", "VQA_DCT_FCH=3",
                                   "VQA_SSIM_VARIANT=1", "VQA_SSIM_VARIANT=4", "VQA_NMS_VARIANT=1", "VQA_NMS_VARIANT=2", "VQA_HYST_SUB=1",
-                                  "VQA_HYST_SUB=5", "VQA_HYST_WIDE=1", "VQA_HYST_STATS=1", "VQA_OVERLAP=1"])
+                                  "VQA_HYST_SUB=5", "VQA_HYST_WIDE=1", "NONE=0"])
 def test_ab_knob_variants_keep_parity(knob):
-    """Every A/B kernel variant kept in the library for re-measurement still matches the oracle
-    (the knobs are read once per process => one subprocess per setting)."""
+    """LAB build (csrc/lab/libvqa_hip_lab.so, loaded through VQA_LIB_PATH): every superseded kernel variant kept for
+    re-measurement (LAB_NOTES.md) still matches the oracle (selectors are read once per process => one subprocess per
+    setting; NONE=0 is the lab build with every selector at its shipped default)."""
     import subprocess
     import sys
+    from rtvqa_amd import _native as N
     k, v = knob.split("=")
-    env = dict(os.environ)
+    env = dict(os.environ, VQA_LIB_PATH=N.LAB_LIB_PATH)
     env[k] = v
-    r = subprocess.run([sys.executable, "-c", _VARIANT_CODE % REPO_ROOT], env=env, capture_output=True, text=True, timeout=600, cwd=REPO_ROOT)
+    code = _VARIANT_CODE.replace("@FLAVOUR@", "3").replace("@STATS@", "0") % REPO_ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=REPO_ROOT)
     assert r.returncode == 0 and "VARIANT-OK" in r.stdout, (knob, r.stdout[-300:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("overlap,stats", [("0", 0), ("1", 1), ("", 0)])
+def test_shipped_library_options_keep_parity(overlap, stats):
+    """The shipped library's two options: VQA_OVERLAP (the environment's initial value of VQA_OPT_OVERLAP; default on)
+    and VQA_OPT_HYST_STATS.  Neither changes a result."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("VQA_LIB_PATH", None)
+    env.pop("VQA_OVERLAP", None)
+    if overlap:
+        env["VQA_OVERLAP"] = overlap
+    code = _VARIANT_CODE.replace("@FLAVOUR@", "0").replace("@STATS@", str(stats)) % REPO_ROOT
+    code = code.replace("eng = rtvqa_amd.Engine(0)\n", "eng = rtvqa_amd.Engine(0)\nassert eng.get_option(N.OPT_OVERLAP) == %d\n" % (0 if overlap == "0" else 1))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=REPO_ROOT)
+    assert r.returncode == 0 and "VARIANT-OK" in r.stdout, (overlap, stats, r.stdout[-300:], r.stderr[-1500:])
+
+
+def test_overlap_option_toggles_within_one_context(engine):
+    """VQA_OPT_OVERLAP flips between submits of one ctx; records are identical (only the diagnostic hyst_steps may differ)."""
+    from rtvqa_amd import _native as N
+    fr = _frames("natural", 6, 270, 480, seed=31)
+    assert engine.get_option(N.OPT_OVERLAP) == 1  # the product's default
+    try:
+        a = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        engine.set_overlap(False)
+        b = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        engine.set_overlap(True)
+        c = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        assert _stable(a) == _stable(b) == _stable(c)
+        engine.complexity_submit(fr[1:], prev0=fr[0], mask=N.M_EDGE)
+        assert engine.lib.vqa_set_option(engine.ctx, N.OPT_OVERLAP, 0) == N.VQA_ERR_STATE  # not while a batch is pending
+        engine.complexity_wait()
+        assert engine.lib.vqa_set_option(engine.ctx, 99, 0) == N.VQA_ERR_INVALID
+    finally:
+        engine.set_overlap(True)
+
+
+_DRAIN_CODE = (
+    "import sys, numpy as np; sys.path.insert(0, %r)\n"
+    "import rtvqa_amd\n"
+    "from rtvqa_amd import _native as N, synth\n"
+    "from rtvqa_amd.engine import bgr_planes\n"
+    "from oracle import c_oracle as co\n"
+    "from oracle import pipeline as pl\n"
+    "h, w = 270, 480\n"
+    "fr = synth.s_natural(5, h, w, seed=17)\n"
+    "eng = rtvqa_amd.Engine(0)\n"
+    "assert eng.lib.vqa_build_flavour() & N.FLAVOUR_TEST_SEAMS\n"
+    "eng.set_overlap(@OVERLAP@)\n"
+    "failed = 0\n"
+    "for attempt in range(4):\n"   # the N-th reservation of the ctx fails exactly once; every other call must be exact
+    "    try:\n"
+    "        rec = eng.complexity(fr[1:], prev0=fr[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)\n"
+    "        q = eng.quality(fr[:2], fr[1:3], bgr_planes(h, w), N.SSIM_GAUSS)\n"
+    "    except N.VqaError as e:\n"
+    "        assert e.status == N.VQA_ERR_OOM and 'test seam' in str(e), str(e)\n"
+    "        failed += 1\n"
+    "        eng._pending_c = eng._pending_q = None\n"
+    "        buf = (N.VqaFrameMetrics * 4)()\n"
+    "        assert eng.lib.vqa_complexity_wait(eng.ctx, buf, 4) == N.VQA_ERR_STATE  # nothing is pending after a failed submit\n"
+    "        continue\n"
+    "    for i in range(4):\n"
+    "        g, gp = co.bgr2gray(fr[i + 1]), co.bgr2gray(fr[i])\n"
+    "        assert (rec[i]['hist_gray'] == co.hist_u8(g)).all(), ('hist', attempt, i)\n"
+    "        assert int(rec[i]['edge_count']) == co.canny(g, 100, 200)[0] and not rec[i]['hyst_overflow'], ('canny', attempt, i)\n"
+    "        nb, sad, hist = co.block_sad(gp, g, 7)\n"
+    "        assert int(rec[i]['sad_sum']) == sad and (rec[i]['mv_d2_hist'] == hist).all(), ('sad', attempt, i)\n"
+    "        e, l1, _ = co.dct8x8(gp, g)\n"
+    "        assert abs(rec[i]['dct_energy'] - e) <= 1e-4 * e and abs(rec[i]['temporal_dct_l1'] - l1) <= 1e-4 * l1, ('dct', attempt, i)\n"
+    "    sse, ssim = pl.frame_quality(fr[0], fr[1], bgr_planes(h, w), 'gauss')\n"
+    "    for p in range(3):\n"
+    "        assert int(q[0, p]['sse']) == sse[p] and abs(q[0, p]['ssim'] - ssim[p]) <= 1e-4 * abs(ssim[p]), ('ssim', attempt, p)\n"
+    "print('DRAIN-OK', failed)\n"
+)
+
+
+@pytest.mark.parametrize("overlap", [1, 0])
+@pytest.mark.parametrize("fail_at", [1, 3, 4, 5, 6, 8, 10, 11, 14, 16, 20, 27])
+def test_failed_submit_is_drained_and_the_context_stays_usable(fail_at, overlap):
+    """LAB build, VQA_FAIL_ENSURE_AT=N: the N-th scratch reservation of the context reports VQA_ERR_OOM.  A full-suite
+    complexity submit from host frames makes 10 reservations (1-2 staging, copies already enqueued behind them; 3 results;
+    4 gray planes; 5 DCT partials, gray + histogram kernels enqueued; 6-10 Canny's, AFTER the fork: block-SAD is then in
+    flight on a side stream), the quality submit 4 more (11-14); 15-28 are the same points of the second round, where
+    nothing is reallocated.  The failing submit must return the error with
+    nothing pending and nothing in flight, and the SAME context must then return oracle-exact records, with the
+    side-stream overlap on and off (video_processing.py:295-297: log, re-raise, nothing left running)."""
+    import subprocess
+    import sys
+    from rtvqa_amd import _native as N
+    env = dict(os.environ, VQA_LIB_PATH=N.LAB_LIB_PATH, VQA_FAIL_ENSURE_AT=str(fail_at))
+    code = _DRAIN_CODE.replace("@OVERLAP@", str(overlap)) % REPO_ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=REPO_ROOT)
+    assert r.returncode == 0 and "DRAIN-OK 1" in r.stdout, (fail_at, overlap, r.stdout[-300:], r.stderr[-1500:])
 
 
 def test_hysteresis_overflow_is_flagged():
     """The tail's round bound exists so the grid always drains; hitting it must SAY so (hyst_overflow = 1) instead of
-    returning a silent under-count.  Forced here with VQA_HYST_MAX_ROUNDS=1 (read once per process => subprocess)."""
+    returning a silent under-count.  Forced here with the LAB build's VQA_HYST_MAX_ROUNDS=1 seam (subprocess); the
+    shipped library has no such switch and must report the full count."""
     import subprocess
     import sys
     code = (
@@ -767,18 +870,59 @@ def test_hysteresis_overflow_is_flagged():
         "rec = eng.complexity(fr, mask=N.M_EDGE)\n"
         "print('RESULT', int(rec[0]['hyst_overflow']), int(rec[0]['edge_count']))\n" % REPO_ROOT
     )
+    from rtvqa_amd import _native as N
     out = {}
-    for rounds in ("1", ""):
-        env = dict(os.environ)
+    for rounds in ("1", "", "shipped"):
+        env = dict(os.environ, VQA_LIB_PATH=N.LAB_LIB_PATH)
         env.pop("VQA_HYST_MAX_ROUNDS", None)
-        if rounds:
+        if rounds == "shipped":  # the variable is set, the shipped library must ignore it
+            env.pop("VQA_LIB_PATH")
+            env["VQA_HYST_MAX_ROUNDS"] = "1"
+        elif rounds:
             env["VQA_HYST_MAX_ROUNDS"] = rounds
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-800:]
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
         out[rounds] = (int(line[1]), int(line[2]))
     assert out[""][0] == 0 and out["1"][0] == 1, out
+    assert out["shipped"] == out[""], out
     assert out["1"][1] < out[""][1], out  # the bounded run is an under-count, and says so
+
+
+def test_results_are_bit_identical_run_to_run(engine):
+    """Every float sum goes through per-block partials and a fixed-order finalize, every integer through exact atomics:
+    the same batch must return the same bytes every time - alone, and while a second context keeps the chip busy with
+    other kernels (waves of one workgroup then drift apart, which is what exposes a missing barrier).  Round 4's first
+    two-rows-per-barrier SSIM kernel had a read/overwrite race on an LDS row buffer that passed every parity test;
+    the bench's serial-versus-timed comparison caught it, and this test is its permanent form."""
+    import rtvqa_amd
+    from rtvqa_amd import _native as N
+    from rtvqa_amd.engine import bgr_planes
+    h, w, n = 1080, 1920, 24
+    d = engine.upload(_frames("natural", n + 1, h, w, seed=41))
+    ref, dist = d.slice(0, n), d.slice(1, n + 1)
+    planes = bgr_planes(h, w)
+    q0 = engine.quality(ref, dist, planes, N.SSIM_GAUSS)
+    f0 = engine.quality(ref, dist, planes, N.SSIM_FFMPEG)
+    c0 = engine.complexity(dist, prev0=d.frame(0), mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+    with rtvqa_amd.Engine(engine.device) as other:
+        for i in range(12):
+            busy = i % 3 != 0
+            if busy:  # the other context's full suite runs next to the kernels under test
+                other.complexity_submit(dist, d.frame(0), N.M_ALL, other.make_params(dct_mode=N.DCT_BLOCK8))
+            q = engine.quality(ref, dist, planes, N.SSIM_GAUSS)
+            f = engine.quality(ref, dist, planes, N.SSIM_FFMPEG) if i % 4 == 1 else None
+            if busy:
+                c = other.complexity_wait()
+                assert _stable(c) == _stable(c0), i
+                other.quality_submit(ref, dist, planes, N.SSIM_GAUSS)
+                c = engine.complexity(dist, prev0=d.frame(0), mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+                q2 = other.quality_wait()
+                assert _stable(c) == _stable(c0), i
+                assert (q2["sse"].tobytes(), q2["ssim"].tobytes()) == (q0["sse"].tobytes(), q0["ssim"].tobytes()), i
+            assert (q["sse"].tobytes(), q["ssim"].tobytes()) == (q0["sse"].tobytes(), q0["ssim"].tobytes()), i
+            if f is not None:
+                assert f["ssim"].tobytes() == f0["ssim"].tobytes(), i
 
 
 def test_region_of_interest_padded_rows(engine):
