@@ -1,16 +1,18 @@
 # After `gpurun -- bash scripts/gpu_round_end.sh <round>`: copy the judged summaries from gpurun_out/ (scratch) into
-# profiles/ (tracked).  usage: bash scripts/collect_profiles.sh [round_tag, default round3]
+# profiles/ (tracked).  usage: bash scripts/collect_profiles.sh [round_tag, default round4]
 set -e
-R=${1:-round3}
+R=${1:-round4}
 cd "$(dirname "$0")/.."
-for t in c2 c3 c2ff c4 c3fb c3noise; do
+for t in c2 c3 c2ff c4 c3fb c3noise c3ref; do
   f=$(ls -t gpurun_out/prof_final_$t/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" profiles/${R}_${t}_kernel_stats.csv
   [ -f gpurun_out/bench_final_$t.log ] && tail -1 gpurun_out/bench_final_$t.log > profiles/${R}_${t}_bench.json
+  [ -f gpurun_out/bench_final_${t}_serial.log ] && grep '^{' gpurun_out/bench_final_${t}_serial.log | tail -1 > profiles/${R}_${t}_serial_bench.json
 done
 for t in c2 c3 c4; do
   [ -f gpurun_out/${R}_${t}_pmc.json ] && cp gpurun_out/${R}_${t}_pmc.json profiles/${R}_${t}_pmc.json
 done
 [ -f gpurun_out/${R}_c3_valu.json ] && cp gpurun_out/${R}_c3_valu.json profiles/${R}_c3_valu.json
 [ -f gpurun_out/clock_trace.json ] && cp gpurun_out/clock_trace.json profiles/${R}_c3_clock.json
+[ -f gpurun_out/ssim_clock.json ] && cp gpurun_out/ssim_clock.json profiles/${R}_ssim_clock.json
 ls -la profiles/ | grep ${R}

@@ -1,10 +1,10 @@
 # Round-end artefacts: GPU tests, smoke, PMC passes, then bench lines + rocprofv3 --kernel-trace --stats.
 # The PMC passes and their summary come FIRST: bench.py reads roofline.traffic from the newest
 # profiles/round<NN>_<workload>_pmc.json whose source hashes match, so the bench lines recorded afterwards carry the
-# traffic measured on the same sources (the old order shipped bench JSONs with "stale" traffic).
-# usage (from the repo root, on the GPU box): VQA_GIT_SHA=<sha> bash scripts/gpu_round_end.sh [round3]
+# traffic measured on the same sources.
+# usage (from the repo root, on the GPU box): VQA_GIT_SHA=<sha> bash scripts/gpu_round_end.sh [round4]
 set -o pipefail
-R=${1:-round3}
+R=${1:-round4}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out
 timeout -k 10 1000 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider > $ROOT/gpurun_out/final_pytest.log 2>&1; rc=$?
@@ -19,6 +19,7 @@ cp profiles/${R}_*_pmc.json $ROOT/gpurun_out/ 2>/dev/null
 bash scripts/gpu_profile.sh final_c3 --steps 10 --warmup 2 || exit 1
 bash scripts/gpu_profile.sh final_c2 --workload c2 --steps 10 --warmup 2 --cpu-sample 32 || exit 1
 bash scripts/gpu_profile.sh final_c4 --workload c4 --steps 5 --warmup 2 --cpu-sample 8 || exit 1
+bash scripts/gpu_profile.sh final_c3ref --workload c3ref --steps 3 --warmup 1 --cpu-sample 8 || exit 1
 bash scripts/gpu_profile.sh final_c2ff --workload c2 --steps 10 --warmup 2 --ssim-mode ffmpeg --cpu-sample 0 --e2e-steps 0 || exit 1
 bash scripts/gpu_profile.sh final_c3noise --content noise --steps 5 --warmup 2 --cpu-sample 0 --e2e-steps 0 || exit 1
 bash scripts/gpu_profile.sh final_c3fb --motion farneback --batch 64 --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 || exit 1

@@ -47,6 +47,7 @@ if __name__ == "__main__":
         kind = sys.argv[1]
         for v in sys.argv[2:]:
             env = dict(os.environ)
+            env.setdefault("VQA_LIB_PATH", os.path.join(REPO, "real-time-video-quality-analysis_amd", "csrc", "lab", "libvqa_hip_lab.so"))  # selectors: lab build only
             env["VQA_SSIM_VARIANT" if kind == "ssim" else "VQA_DCT_VARIANT"] = v
             print("%s variant %s" % (kind, v), flush=True)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", kind], env=env, timeout=300)

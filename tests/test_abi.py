@@ -127,12 +127,12 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b|#include\s+\"[^\"]*oracle", txt, flags=re.M), f
 
 
-def _build_demo(tmp_path):
+def _build_demo(tmp_path, name="vqa_demo"):
     import subprocess
-    exe = str(tmp_path / "vqa_demo")
+    exe = str(tmp_path / name)
     libdir = os.path.join(REPO, "real-time-video-quality-analysis_amd", "csrc")
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), "-o", exe,
-                           os.path.join(REPO, "examples", "vqa_demo.c"), "-L", libdir, "-lvqa_hip",
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-pthread", "-I", os.path.join(REPO, "include"), "-o", exe,
+                           os.path.join(REPO, "examples", name + ".c"), "-L", libdir, "-lvqa_hip",
                            "-Wl,-rpath," + libdir, "-lm"])
     return exe
 
@@ -149,6 +149,28 @@ def test_plain_c_host_links_against_the_abi(tmp_path):
     if n.value == 0:
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_multi_device_c_host_builds_and_refuses_to_run_without_a_device(tmp_path):
+    """examples/vqa_multi.c (BASELINE configs[4] as a plain-C host: one thread + context per device, one all-reduce)."""
+    import subprocess
+    from rtvqa_amd import _native as N
+    exe = _build_demo(tmp_path, "vqa_multi")
+    n = C.c_int(-1)
+    N.load().vqa_device_count(C.byref(n))
+    if n.value == 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_multi_device_c_host_runs_with_the_devices_present(tmp_path):
+    """On the one-GPU test box: 1 device, 6 x 2160p frames, 2 passes, then vqa_comm_create + vqa_allreduce over RCCL.
+    (On a multi-GPU node the same binary takes every device; that run has not happened yet.)"""
+    import subprocess
+    r = subprocess.run([_build_demo(tmp_path, "vqa_multi"), "0", "6", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "vqa_multi ok" in r.stdout, r.stdout + r.stderr
+    assert re.search(r"all-reduce over \d+ device\(s\): \d+ frames", r.stdout) or "RCCL not installed" in r.stdout
 
 
 @pytest.mark.gpu
