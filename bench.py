@@ -6,10 +6,11 @@
          --master-port P bench.py --gpus N --steps K --warmup W   (N > 1, one rank per GPU)
 
 A "step" is one pass of the selected workload over one device-resident batch of
-frames.  `value` is timed on the product's own configuration: quality kernels on a
-second context of the device (--streams 2), block-SAD and the Canny chain on the
-library's side streams (VQA_OPT_OVERLAP, its default) and two batches in flight
-(--inflight 2: step i+1 is submitted before step i is waited for), per-kernel
+frames.  `value` is timed on the product's own configuration: block-SAD and the
+Canny chain on the library's side streams (VQA_OPT_OVERLAP, its default) and two
+batches in flight, each on its own context (--inflight 2: step i+1 is submitted
+before step i is waited for - what a host that streams batches does; measured best
+of {1,2} contexts per batch x {1,2,3} batches in flight, LAB_NOTES.md), per-kernel
 profiling OFF.  Because overlapped kernels share the GPU, their event times say
 nothing about a kernel alone; so after the timed region a SERIAL pass runs the same
 steps on one context with the overlap off and HIP-event profiling on: it fills
@@ -64,7 +65,7 @@ WORKLOADS = {
                name="1920x1080 full suite (motion-SAD, DCT, temporal-DCT, Canny, ORB count, gray+colour hist) + PSNR/SSIM"),
     "c4": dict(h=2160, w=3840, batch=64, full=True, name="3840x2160 full suite + PSNR/SSIM"),
     "c3ref": dict(h=1080, w=1920, batch=64, full=True,
-                  defaults=dict(motion="farneback", dct_mode="full", ssim_mode="ffmpeg", pixfmt="yuv420p"),
+                  defaults=dict(motion="farneback", dct_mode="full", ssim_mode="ffmpeg", pixfmt="yuv420p", streams=2, inflight=1),
                   name="1920x1080 reference-true suite (Farneback motion, full-frame DCT + temporal DCT, Canny, ORB count, "
                        "gray+colour hist) + FFmpeg psnr/vf_ssim on yuv420p planes"),
 }
@@ -355,10 +356,12 @@ def main():
     ap.add_argument("--e2e-steps", type=int, default=6, help="steps of the PCIe-inclusive end_to_end measurement (0 = skip)")
     ap.add_argument("--e2e-batch", type=int, default=64, help="frames per step of the end_to_end measurement")
     ap.add_argument("--ssim-mode", default=None, choices=["gauss", "ffmpeg"], help="default: gauss (c3ref: ffmpeg)")
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
-                    help="2 (default): quality kernels on a second context of the device, next to the complexity kernels; 1: one context")
-    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2],
-                    help="2 (default): step i+1 is submitted before step i is waited for (two sets of contexts, ping-ponged); 1: submit, wait")
+    ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
+                    help="1 (default): quality and complexity kernels of a batch on one context; 2: the quality kernels on a "
+                         "second context of the device (default for c3ref)")
+    ap.add_argument("--inflight", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="batches in flight: step i+1 is submitted before step i is waited for, each on its own set of "
+                         "contexts (default 2; c3ref: 1 - its Farneback / full-frame DCT scratch is GiB-sized per context)")
     ap.add_argument("--pixfmt", default=None, choices=["bgr24", "yuv420p"],
                     help="planes PSNR/SSIM compare: bgr24 (default: B,G,R of the packed frames) or yuv420p (Y + "
                          "quarter-size U,V derived from the same frames: what FFmpeg compares for an H.264 clip)")
@@ -390,7 +393,8 @@ def main():
         raise SystemExit("--stub-engine is a CPU rehearsal: use --backend gloo")
 
     wl = WORKLOADS[args.workload]
-    for k, v in dict(dict(ssim_mode="gauss", pixfmt="bgr24", dct_mode="block8", motion="sad"), **wl.get("defaults", {})).items():
+    for k, v in dict(dict(ssim_mode="gauss", pixfmt="bgr24", dct_mode="block8", motion="sad", streams=1, inflight=2),
+                     **wl.get("defaults", {})).items():
         if getattr(args, k) is None:
             setattr(args, k, v)
     h, w, full = wl["h"], wl["w"], wl["full"]

@@ -49,9 +49,20 @@ static inline int ssim_strips(int h, long long groups /* workgroups per strip ro
     return ns > cap ? cap : ns;
 }
 // rows a strip owns: a multiple of 11 (k_ssim_gauss consumes rows in groups of 11 and owns whole groups)
-// rows a strip owns: a multiple of 22 (k_ssim_gauss_p2 consumes rows in groups of 22 and owns whole groups; the lab
-// build's one-row kernel needs a multiple of 11)
-static inline int ssim_strip_rows(int h, int ns) { return ((h - 10 + ns - 1) / ns + 21) / 22 * 22; }
+#ifndef SSIM_ROWS
+#define SSIM_ROWS 8   // rows per LDS round trip of k_ssim_gauss_p2 (8 = shipped; 2, 4 = measurement builds)
+#endif
+// rows a strip owns: a multiple of 6 * SSIM_ROWS (k_ssim_gauss_p2 consumes rows in groups of that size and owns whole
+// groups); in the lab build also of 11 (its one-row kernel owns groups of 11)
+static inline int ssim_strip_rows(int h, int ns)
+{
+#ifdef VQA_AB_VARIANTS
+    const int m = 66 * (SSIM_ROWS == 8 ? 4 : SSIM_ROWS);
+#else
+    const int m = (SSIM_ROWS == 8 ? 3 : 6) * SSIM_ROWS;
+#endif
+    return ((h - 10 + ns - 1) / ns + m - 1) / m * m;
+}
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -273,25 +284,36 @@ __global__ __launch_bounds__(QT) SSIM_WAVES void k_ssim_gauss(const uint8_t *__r
 #endif // VQA_AB_VARIANTS
 
 // ---------------------------------------------------------------------------
-// k_ssim_gauss_p2: the same arithmetic with HALF the LDS read traffic.  Round 4 found the kernel power-bound (the
-// chip sits at its ~1.27 kW cap and sets the clock accordingly; removing 7 % of the instructions changed nothing),
-// with the 11 ds_read_b128 per pixel worth 19 % of a launch's energy (LAB_NOTES.md, profiles/round4_ssim_clock.json).
-// Here TWO rows go through LDS per barrier and a LANE PAIR shares the horizontal pass of two adjacent columns:
-// lane 2j filters columns (2j, 2j+1) of the first row, lane 2j+1 the same columns of the second row.  Each lane reads
-// the 12 columns 2j .. 2j+11 once (12 ds_read_b128 for two output pixels instead of 22) and runs the same 44 packed
-// FMAs and two SSIM formulas a lane of k_ssim_gauss runs for its two rows.  The vertical pass is unchanged (one
-// column per thread, rolling 11-slot accumulators).  LDS rows are QT + 1 float4 apart, so the two lanes of a pair sit
-// in different bank groups and every ds_read_b128 stays conflict-free.
+// k_ssim_gauss_p2<QT, R>: the same arithmetic with a FIFTH of the LDS read traffic.  Round 4 found the kernel
+// POWER-bound: the chip sits at its ~1.27 kW cap and sets the clock to fit (1.9 GHz under round 3's kernel); removing
+// 7 % of the instructions changed neither time nor energy, while the 11 ds_read_b128 per output pixel were worth 19 %
+// of a launch's energy (LAB_NOTES.md L4, profiles/round4_ssim_clock.json).  So the horizontal pass is shared:
+// R rows go through LDS per round trip and a GROUP OF R LANES shares R adjacent columns - lane R j + i filters the
+// columns R j .. R j + R - 1 of the step's i-th row.  Each lane reads the 10 + R columns R j .. R j + R + 9 once
+// ((10 + R) / R reads per output pixel: 6 for R = 2, 3.5 for R = 4, 2.25 for R = 8, against 11) and runs the same
+// 22 R packed FMAs and R SSIM formulas a lane of the one-row kernel runs for its R rows.  The vertical pass is
+// unchanged (one column per thread, rolling accumulators) except that the ring has 12 slots (11 live + 1 spare) so
+// that R divides it and 3 or 6 steps make a loop iteration.  LDS rows are QT + 1 float4 apart: the lanes of a group
+// sit in different bank groups and every ds_read_b128 stays conflict-free.
+// Measured per 256 x 1080p x 3-plane launch (same box, interleaved): one row 4.51-4.66 ms, R = 2 4.33-4.39,
+// R = 4 (double-buffered) 4.08-4.25, R = 8 (single buffer, two barriers per step: 33 KB LDS, 4 waves/SIMD) 4.14
+// against 4.23-4.25 for R = 4 on that box; R = 8 double-buffered (66 KB, 2 waves/SIMD) 4.54 at the full 2.38 GHz:
+// no longer power-bound but latency-bound.
 // ---------------------------------------------------------------------------
-template <int QT>
+template <int QT, int R>
 __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ dist,
                                                       int64_t ref_fs, int64_t dist_fs, plane_group g, int64_t row_stride,
                                                       int step, int w, int h, int ncb, int nstrips, int QS,
                                                       double *__restrict__ partials, int64_t partial_plane_stride,
                                                       int n_planes, vqa_plane_metrics *__restrict__ res)
 {
+    static_assert(R == 2 || R == 4 || R == 8, "rows per barrier = lanes per group = adjacent columns per lane");
     constexpr int QOUT = QT - 10;
-    __shared__ float4 vb[2][2][QT + 1]; // [step parity][row of the pair][column]
+    constexpr int NS = 12;                  // accumulator ring: 11 live output rows + 1 spare slot, so that R divides the ring
+    constexpr int ST = R == 8 ? 3 : 6;      // steps per loop iteration
+    constexpr int GR = ST * R;              // rows per loop iteration: a whole number of ring turns
+    constexpr int NB = R == 8 ? 1 : 2;      // LDS row buffers: double (one barrier per step) or, R = 8 probe, single (two)
+    __shared__ float4 vb[NB][R][QT + 1];    // [step parity][row of the step][column]
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
     const int f = blockIdx.y;
@@ -308,18 +330,20 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
     const bool last_cb = cb == ncb - 1, last_sb = sb == nstrips - 1;
     const bool in_c = xin < w;
     const bool own_c = in_c && (last_cb || t < QOUT);
-    // horizontal role: columns hc, hc + 1 of row (t & 1) of the step's pair
-    const int hc = t & ~1, hrow = t & 1;
-    const bool out_a = hc < QOUT && xs + hc < ow, out_b = hc + 1 < QOUT && xs + hc + 1 < ow;
+    // horizontal role: the R adjacent columns hc .. hc + R - 1 of row (t % R) of the step
+    const int hc = t & ~(R - 1), hrow = t & (R - 1);
+    bool out_j[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) out_j[j] = hc + j < QOUT && xs + hc + j < ow;
     const int64_t base = g.offset[ch] + (int64_t)ys * row_stride;
     const uint8_t *rbase = ref + (int64_t)f * ref_fs + base;
     const uint8_t *dbase = dist + (int64_t)f * dist_fs + base;
     const uint32_t coff = (uint32_t)((in_c ? xin : 0) * step);
 
     typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 acc[11];
+    f4 acc[NS];
 #pragma unroll
-    for (int s = 0; s < 11; s++) acc[s] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NS; s++) acc[s] = f4{0.f, 0.f, 0.f, 0.f};
     float ssim_acc = 0.f;
     uint32_t sse_acc = 0;
     float sse_sq = 0.f, sse_xy = 0.f;
@@ -331,13 +355,15 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
     };
     uint32_t nr = ld(rres, 0), nd = ld(dres, 0);
 
-    // LDS double buffering: a step stores into the buffer the step BEFORE LAST read from, and the one barrier per step
-    // orders that.  A 22-row group has 11 steps - an odd number - so the buffer of step st is (st & 1) ^ (group parity):
-    // gpar flips per group (the first version used st & 1 alone: the last step of a group and the first step of the
-    // next then shared a buffer with no barrier between read and overwrite - a race that every parity test survived
-    // and that the bench's serial-vs-timed comparison caught; tests/test_gpu_parity.py now repeats a batch 40 times).
+    // LDS double buffering: step st stores into buffer st & 1, the buffer the step BEFORE LAST read from; the one barrier
+    // per step orders that.  A loop iteration has an EVEN number of steps (6), so the parity carries across iterations
+    // (R = 8, a measurement build, has 3: there the buffer is (st & 1) ^ gpar with gpar flipping per iteration).
+    // (Round 4's first version had 11 steps per iteration: its last step and the next iteration's first then shared a
+    // buffer with no barrier between read and overwrite - a race that every parity test survived and that the bench's
+    // serial-vs-timed comparison caught; test_results_are_bit_identical_run_to_run is its permanent test.)
     int gpar = 0;
-    // vertical pass of one input row (as k_ssim_gauss); emit: store the completed output row into vb[sp][slot][t]
+    // vertical pass of one input row; p = r mod NS (static after unrolling).  Input row r is tap k of output row r - k,
+    // kept in ring slot (r - k) mod NS.  emit: store the completed output row r - 10 into vb[sp][slot][t]
     auto vrow = [&](const int p, const int r, const bool emit, const int sp, const int slot) {
         const uint32_t cr = nr, cd = nd;
         {
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
         sse_xy = fmaf(own_f, v1.y, sse_xy);
 #pragma unroll
         for (int k = 0; k < 11; k++) {
-            const int s = (p - k + 11) % 11;
+            const int s = (p - k + NS) % NS;
             if (k == 0) {
                 acc[s].xy = gw(0) * xy;
                 acc[s].zw = gw(0) * v1;
@@ -361,61 +387,72 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
                 acc[s].zw = __builtin_elementwise_fma(f2{gw(k), gw(k)}, v1, acc[s].zw);
             }
         }
-        if (emit) *(f4 *)&vb[sp][slot][t] = acc[(p + 1) % 11];
+        if (emit) *(f4 *)&vb[sp][slot][t] = acc[(p + NS - 10) % NS];
     };
-    // horizontal pass + SSIM of the step's two output rows: this lane's row is hrow (rows_out = 1: only row 0 exists)
-    auto hpass = [&](const int sp, const int rows_out) {
+    // horizontal pass + SSIM of the step's output rows lo .. hi - 1 (wave-uniform bounds): this lane's row is hrow
+    auto hpass = [&](const int sp, const int lo, const int hi) {
         __syncthreads();
-        if (out_a && hrow < rows_out) {
+        if (out_j[0] && hrow >= lo && hrow < hi) {
             const float4 *src = &vb[sp][hrow][hc];
-            f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, b0 = {0.f, 0.f}, b1 = {0.f, 0.f};
+            f2 o0[R], o1[R];
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
+            for (int j = 0; j < R; j++) o0[j] = o1[j] = f2{0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 10 + R; i++) {
                 const float4 q = src[i];
-                if (i < 11) {
-                    a0 = __builtin_elementwise_fma(f2{gw(i), gw(i)}, f2{q.x, q.y}, a0);
-                    a1 = __builtin_elementwise_fma(f2{gw(i), gw(i)}, f2{q.z, q.w}, a1);
-                }
-                if (i > 0) {
-                    b0 = __builtin_elementwise_fma(f2{gw(i - 1), gw(i - 1)}, f2{q.x, q.y}, b0);
-                    b1 = __builtin_elementwise_fma(f2{gw(i - 1), gw(i - 1)}, f2{q.z, q.w}, b1);
-                }
+#pragma unroll
+                for (int j = 0; j < R; j++)
+                    if (i - j >= 0 && i - j < 11) {
+                        o0[j] = __builtin_elementwise_fma(f2{gw(i - j), gw(i - j)}, f2{q.x, q.y}, o0[j]);
+                        o1[j] = __builtin_elementwise_fma(f2{gw(i - j), gw(i - j)}, f2{q.z, q.w}, o1[j]);
+                    }
             }
-            const float sb_ = ssim_centered(b0, b1);
-            ssim_acc += ssim_centered(a0, a1) + (out_b ? sb_ : 0.f);
+            float sum = ssim_centered(o0[0], o1[0]);
+#pragma unroll
+            for (int j = 1; j < R; j++) {
+                const float v = ssim_centered(o0[j], o1[j]);
+                sum += out_j[j] ? v : 0.f;
+            }
+            ssim_acc += sum;
         }
     };
 
-    // 22 rows (two turns of the accumulator ring, 11 steps of two rows) per iteration; QS is a multiple of 22, so a
-    // strip's owned rows are its full iterations and the rest (10 halo rows, or the last strip's leftover) goes through
-    // one guarded copy below.
-    const int nfull = nrows / 22;
+    // GR rows per iteration; QS is a multiple of GR, so a strip's owned rows are its full iterations and the rest (10
+    // halo rows, or the last strip's leftover) goes through one guarded copy below.
+    const int nfull = nrows / GR;
     int flush = 0;
     for (int gI = 0; gI < nfull; gI++) {
-        const int r0 = gI * 22;
-        if (++flush == 11) { sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy); sse_sq = sse_xy = 0.f; flush = 0; } // 242 rows
+        const int r0 = gI * GR;
+        if (++flush == 240 / GR) { sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy); sse_sq = sse_xy = 0.f; flush = 0; } // <= 240 rows
 #pragma unroll
-        for (int st = 0; st < 11; st++) {
-            const bool emit = st >= 5 || gI > 0; // rows 0..9 of a strip complete no output row
-            vrow((2 * st) % 11, r0 + 2 * st, emit, (st & 1) ^ gpar, 0);
-            vrow((2 * st + 1) % 11, r0 + 2 * st + 1, emit, (st & 1) ^ gpar, 1);
-            if (emit) hpass((st & 1) ^ gpar, 2);
+        for (int st = 0; st < ST; st++) {
+            const int sp = NB == 1 ? 0 : ((ST & 1) ? ((st & 1) ^ gpar) : (st & 1));
+            if (NB == 1) __syncthreads(); // single buffer: the previous step's readers are done
+#pragma unroll
+            for (int j = 0; j < R; j++) vrow((R * st + j) % NS, r0 + R * st + j, gI > 0 || R * st + j >= 10, sp, j);
+            const int lo0 = 10 - R * st; // rows 0..9 of a strip complete no output row
+            const int lo = gI > 0 ? 0 : (lo0 > 0 ? lo0 : 0);
+            if (lo < R) hpass(sp, lo, R);
         }
-        gpar ^= 1;
+        if (ST & 1) gpar ^= 1;
     }
     sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy);
     sse_sq = sse_xy = 0.f;
     if (!last_sb) own_f = 0.f; // the halo rows belong to the next strip
     {
-        const int r0 = nfull * 22;
+        const int r0 = nfull * GR;
 #pragma unroll
-        for (int st = 0; st < 11; st++) {
-            const int ra = r0 + 2 * st;
+        for (int st = 0; st < ST; st++) {
+            const int ra = r0 + R * st;
             if (ra < nrows) {
-                const bool emit = ra >= 10, has_b = ra + 1 < nrows;
-                vrow((2 * st) % 11, ra, emit, (st & 1) ^ gpar, 0);
-                if (has_b) vrow((2 * st + 1) % 11, ra + 1, emit, (st & 1) ^ gpar, 1);
-                if (emit) hpass((st & 1) ^ gpar, has_b ? 2 : 1);
+                const int sp = NB == 1 ? 0 : ((ST & 1) ? ((st & 1) ^ gpar) : (st & 1));
+                if (NB == 1) __syncthreads();
+                const int hi = min(R, nrows - ra);
+#pragma unroll
+                for (int j = 0; j < R; j++)
+                    if (j < hi) vrow((R * st + j) % NS, ra + j, ra + j >= 10, sp, j);
+                const int lo = ra >= 10 ? 0 : 10 - ra;
+                if (lo < hi) hpass(sp, lo, hi);
             }
         }
     }
@@ -488,7 +525,7 @@ void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dis
     case 5: LAUNCH_SSIM(256, 2, 0); break; // round 3's shipped kernel (one row per barrier), with round 4's loop structure
 #endif
     default: // the shipped kernel: two rows per barrier, lane pairs share the horizontal pass
-        hipLaunchKernelGGL((k_ssim_gauss_p2<256>), dim3((bpp + 7) / 8 * 8 * count, n), dim3(256), 0, st, ref, dist, ref_frame_stride,
+        hipLaunchKernelGGL((k_ssim_gauss_p2<256, SSIM_ROWS>), dim3((bpp + 7) / 8 * 8 * count, n), dim3(256), 0, st, ref, dist, ref_frame_stride,
                            dist_frame_stride, g, pd.row_stride, pd.pixel_step, w, h, ncb, ns, QS, partials,
                            partial_plane_stride, n_planes, res);
         break;
