@@ -48,6 +48,8 @@ def lib():
         L.vqo_canny_count.argtypes = [u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, u8p,
                                       C.POINTER(C.c_long), C.POINTER(C.c_long)]
         L.vqo_canny_count.restype = C.c_long
+        L.vqo_sobel_l1.argtypes = [u8p, C.c_int, C.c_int, C.c_ssize_t, C.POINTER(C.c_int16), C.POINTER(C.c_int16), C.POINTER(C.c_int32)]
+        L.vqo_sobel_l1.restype = None
         L.vqo_block_sad.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_ssize_t, C.c_int,
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int8)]
         L.vqo_block_sad.restype = C.c_int
@@ -157,6 +159,17 @@ def canny(gray, low=100, high=200, want_map=False):
     if cnt < 0:
         raise MemoryError
     return (cnt, ns.value, nw.value, edges) if want_map else (cnt, ns.value, nw.value)
+
+
+def sobel_l1(gray):
+    """cv2.Canny's gradient stage: (dx, dy) int16 Sobel 3x3 on a replicated border and |dx| + |dy| as int32."""
+    gray = _c(gray)
+    h, w = gray.shape
+    dx, dy = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+    mag = np.zeros((h, w), np.int32)
+    lib().vqo_sobel_l1(_u8(gray), h, w, w, dx.ctypes.data_as(C.POINTER(C.c_int16)), dy.ctypes.data_as(C.POINTER(C.c_int16)),
+                       mag.ctypes.data_as(C.POINTER(C.c_int32)))
+    return dx, dy, mag
 
 
 def block_sad(prev, curr, rng=7, want_mv=False):

@@ -15,6 +15,8 @@ nobody in this repository wrote, so what it computes pins the oracle where the t
   * float64 bilinear resize with half-pixel centres and edge clamping (transform.resize(order=1, mode="edge",
     anti_aliasing=False)): a GEOMETRY pin for cv2.resize INTER_LINEAR (complexity_metrics.py:359,404) - OpenCV's 11-bit
     fixed point must stay within 1 grey level of it; it does not pin OpenCV's rounding
+  * Sobel 3x3 on a replicated border, L1 magnitude (scipy.ndimage.sobel(mode="nearest") on int32): the gradient
+    stage of cv2.Canny(L2gradient=False) (complexity_metrics.py:503)           -> oracle sobel_l1, exact per pixel
   * orthonormal DCT-II (scipy.fft.dctn of SciPy 1.7.1): full-frame energy / L1 and the 8x8-block forms
     (complexity_metrics.py:363-364, :574-579)                                  -> oracle dct_*, 1e-5
 
@@ -139,6 +141,7 @@ def stage2(tmp):
     warnings.filterwarnings("ignore")
     import scipy
     import scipy.fft
+    import scipy.ndimage
     import skimage
     from skimage.feature import corner_fast
     from skimage.measure import shannon_entropy
@@ -176,6 +179,10 @@ def stage2(tmp):
         b0 = scipy.fft.dctn(blocks8(g0), axes=(2, 3), norm="ortho")
         b1 = scipy.fft.dctn(blocks8(g1), axes=(2, 3), norm="ortho")
         rs = resize(g0, (dh, dw), order=1, mode="edge", anti_aliasing=False, preserve_range=True)
+        gi = g0.astype(np.int32)
+        sob = np.abs(scipy.ndimage.sobel(gi, axis=1, mode="nearest")) + np.abs(scipy.ndimage.sobel(gi, axis=0, mode="nearest"))
+        sh, sw = sob.shape
+        wts = (np.arange(sh, dtype=np.int64)[:, None] * 31 + np.arange(sw, dtype=np.int64)[None, :] * 17 + 1) % 1009
         out["frames"][m["name"]] = dict(
             gray_entropy=float(shannon_entropy(g0.astype(np.uint8))),
             color_entropy_sum=float(sum(shannon_entropy(bgr[..., c]) for c in range(3))),
@@ -183,6 +190,8 @@ def stage2(tmp):
             fast9_crc=int(np.sum((ys.astype(np.int64) * 7919 + xs.astype(np.int64) * 104729) % 1000003)),
             dct_full_energy=float((d1 ** 2).sum()), dct_full_l1=float(np.abs(d0 - d1).sum()),
             dct8_energy=float((b1 ** 2).sum()), dct8_l1=float(np.abs(b0 - b1).sum()),
+            sobel_l1_sum=int(sob.sum()), sobel_l1_max=int(sob.max()), sobel_l1_crc=int((sob.astype(np.int64) * wts).sum()),
+            sobel_l1_border_sum=int(sob[0].sum() + sob[-1].sum() + sob[:, 0].sum() + sob[:, -1].sum()),
             resize_float=[round(float(v), 6) for v in rs.ravel()])
     json.dump(out, open(os.path.join(tmp, "results.json"), "w"))
 

@@ -3,8 +3,10 @@ oracle/gen_pins_skimage.py under /opt/conda/bin/python3.9 in the build container
 against the HIP path (-m gpu half).  Neither library is this repository's code, so these are the pins DESIGN.md §3
 calls "pinned by skimage": Gaussian-windowed SSIM (north_star's definition in place of video_processing.py:276),
 MSE / PSNR (video_processing.py:275), the entropy tails (complexity_metrics.py:413-414, :467-473), the FAST-9/16
-corner test (:386-387), the orthonormal DCT sums (:363-364, :574-579) and the bilinear resize GEOMETRY (:359).
-NOT pinned by them: OpenCV's BGR2GRAY / INTER_LINEAR rounding, Canny, Farneback, FFmpeg's vf_ssim integers.
+corner test (:386-387), the orthonormal DCT sums (:363-364, :574-579), the Sobel / L1-magnitude stage of Canny (:503) and
+the bilinear resize GEOMETRY (:359).
+NOT pinned by them: OpenCV's BGR2GRAY / INTER_LINEAR rounding, Canny's NMS / sector test / hysteresis, Farneback,
+FFmpeg's vf_ssim integers.
 """
 import json
 import math
@@ -107,6 +109,20 @@ def test_oracle_fast9_detection_equals_skimage_corner_fast(rec):
     ys, xs = np.nonzero(keep)
     assert n == rec["fast9_count"] == len(ys)
     assert int(np.sum((ys.astype(np.int64) * 7919 + xs.astype(np.int64) * 104729) % 1000003)) == rec["fast9_crc"]
+
+
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_oracle_sobel_stage_of_canny_equals_scipy_ndimage(rec):
+    """cv2.Canny's gradient: 3x3 Sobel on a replicated border, |dx| + |dy| - every pixel, borders included, against
+    scipy.ndimage.sobel(mode="nearest").  (NMS, the TG22 sector test and the hysteresis stay unpinned.)"""
+    g0, _ = gp.gray_for(FRAME_CASE[rec["name"]])
+    dx, dy, mag = co.sobel_l1(g0)
+    assert (np.abs(dx.astype(np.int32)) + np.abs(dy.astype(np.int32)) == mag).all()
+    h, w = mag.shape
+    wts = (np.arange(h, dtype=np.int64)[:, None] * 31 + np.arange(w, dtype=np.int64)[None, :] * 17 + 1) % 1009
+    assert int(mag.sum()) == rec["sobel_l1_sum"] and int(mag.max()) == rec["sobel_l1_max"]
+    assert int((mag.astype(np.int64) * wts).sum()) == rec["sobel_l1_crc"]
+    assert int(mag[0].sum() + mag[-1].sum() + mag[:, 0].sum() + mag[:, -1].sum()) == rec["sobel_l1_border_sum"]
 
 
 @pytest.mark.parametrize("rec", G["frames"], ids=pid)
