@@ -359,10 +359,15 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
     if len(idx) < 2 or hi <= lo:  # unopenable / too short: empty series, as the reference's empty pair list (:95-97)
         return out
     on_device = isinstance(fr, DeviceFrames)
-    if engine is not None or on_device or len(idx) - 1 <= batch_size:
+    if engine is not None or len(idx) - 1 <= batch_size:
         engs = [engine or get_engine()]
     else:
-        engs = list(get_engine_pair())  # host clip, several batches: copy/compute ping-pong
+        # several batches: two contexts, batch k + 1 is submitted before batch k is waited for.  A host clip's copy then
+        # overlaps the other context's kernels; a device-resident clip's kernels keep the chip busy across the wait
+        # (bench.py's --inflight 2: +5 % on the full suite)
+        own = getattr(fr, "_owner", None) if on_device else None  # a DeviceBuffer knows its engine's device; a torch tensor its index
+        dev = (own.engine.device if hasattr(own, "engine") else getattr(getattr(own, "device", None), "index", None)) if own is not None else None
+        engs = list(get_engine_pair(dev))
     params = engs[0].make_params(resize=(resize_width, resize_height), dct_mode=dct_mode, motion_mode=_motion_mode)
     sel = idx[1 + lo:1 + hi]
     prev_i = idx[lo]

@@ -103,7 +103,7 @@ def test_pmc_traffic_goes_null_when_sources_changed(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "REPO", str(tmp_path))
     h = bench.source_hashes()
     good = {"tag": "round9_c3", "frames_per_launch": 128, "git_sha": "abc1234", "source_sha256": h,
-            "kernels": {"k_ssim_gauss<256, 2, 0>": {"hbm_bytes": 1000}}}
+            "kernels": {"k_ssim_gauss_p2<256, 8>": {"hbm_bytes": 1000}, "k_ssim_ffmpeg_fast<3>": {"hbm_bytes": 7}}}
     (prof / "round9_c3_pmc.json").write_text(json.dumps(good))
     (prof / "round2_c3_pmc.json").write_text(json.dumps(dict(good, kernels={"k_ssim_gauss<256, 2, 0>": {"hbm_bytes": 1}})))
     t, src = bench.pmc_traffic("c3", "k_ssim_gauss", 256, True)
@@ -112,6 +112,10 @@ def test_pmc_traffic_goes_null_when_sources_changed(tmp_path, monkeypatch):
     (prof / "round9_c3_pmc.json").write_text(json.dumps(stale))
     t, src = bench.pmc_traffic("c3", "k_ssim_gauss", 256, True)
     assert t is None and src.startswith("stale:")
+    for f in ("vqa_capi.hip", "vqa_kernels.hpp", "vqa_dev.hpp"):  # the orchestration and the shared headers count too
+        (prof / "round9_c3_pmc.json").write_text(json.dumps(dict(good, source_sha256=dict(h, **{f: "0" * 16}))))
+        t, src = bench.pmc_traffic("c3", "k_ssim_gauss", 256, True)
+        assert t is None and src.startswith("stale:") and f in src, f
     nohash = {k: v for k, v in good.items() if k != "source_sha256"}
     (prof / "round9_c3_pmc.json").write_text(json.dumps(nohash))
     assert bench.pmc_traffic("c3", "k_ssim_gauss", 256, True)[0] is None
