@@ -393,10 +393,13 @@ def main():
         raise SystemExit("--stub-engine is a CPU rehearsal: use --backend gloo")
 
     wl = WORKLOADS[args.workload]
-    for k, v in dict(dict(ssim_mode="gauss", pixfmt="bgr24", dct_mode="block8", motion="sad", streams=1, inflight=2),
-                     **wl.get("defaults", {})).items():
+    for k, v in dict(dict(ssim_mode="gauss", pixfmt="bgr24", dct_mode="block8", motion="sad", streams=1), **wl.get("defaults", {})).items():
         if getattr(args, k) is None:
             setattr(args, k, v)
+    if args.inflight is None:
+        # Farneback and the full-frame DCT keep GiB-sized scratch per context and saturate the chip on their own: a second
+        # batch in flight thrashes (measured: c3 + Farneback 2946 fps with one batch in flight, 1684 with two)
+        args.inflight = 1 if (args.motion == "farneback" or args.dct_mode == "full") else 2
     h, w, full = wl["h"], wl["w"], wl["full"]
     B = args.batch or wl["batch"]
     stub = args.stub_engine

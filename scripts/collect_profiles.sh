@@ -13,6 +13,6 @@ for t in c2 c3 c4; do
   [ -f gpurun_out/${R}_${t}_pmc.json ] && cp gpurun_out/${R}_${t}_pmc.json profiles/${R}_${t}_pmc.json
 done
 [ -f gpurun_out/${R}_c3_valu.json ] && cp gpurun_out/${R}_c3_valu.json profiles/${R}_c3_valu.json
-[ -f gpurun_out/clock_trace.json ] && cp gpurun_out/clock_trace.json profiles/${R}_c3_clock.json
-[ -f gpurun_out/ssim_clock.json ] && cp gpurun_out/ssim_clock.json profiles/${R}_ssim_clock.json
+# (clock traces are copied by hand: gpurun_out/ accumulates across rounds, and scripts/clock_trace.py / ssim_clock.py are
+#  separate runs: cp gpurun_out/clock_trace.json profiles/${R}_c3_clock.json after running them in THIS round)
 ls -la profiles/ | grep ${R}
