@@ -15,6 +15,10 @@ nobody in this repository wrote, so what it computes pins the oracle where the t
   * float64 bilinear resize with half-pixel centres and edge clamping (transform.resize(order=1, mode="edge",
     anti_aliasing=False)): a GEOMETRY pin for cv2.resize INTER_LINEAR (complexity_metrics.py:359,404) - OpenCV's 11-bit
     fixed point must stay within 1 grey level of it; it does not pin OpenCV's rounding
+  * BGR -> gray as ITU-R 601 luma of the right channels: Pillow 8.4.0's Image.convert("L") (16-bit fixed point,
+    (R*19595 + G*38470 + B*7471 + 0x8000) >> 16) and the float64 formula 0.299 R + 0.587 G + 0.114 B.  A SEMANTIC pin
+    for cv2.cvtColor(BGR2GRAY) (complexity_metrics.py:327,358,405,493): channel order and weights - OpenCV's 15-bit
+    fixed point must stay within 1 grey level of both; it does not pin OpenCV's rounding   -> oracle bgr2gray, |diff| <= 1
   * Sobel 3x3 on a replicated border, L1 magnitude (scipy.ndimage.sobel(mode="nearest") on int32): the gradient
     stage of cv2.Canny(L2gradient=False) (complexity_metrics.py:503)           -> oracle sobel_l1, exact per pixel
   * orthonormal DCT-II (scipy.fft.dctn of SciPy 1.7.1): full-frame energy / L1 and the 8x8-block forms
@@ -142,6 +146,8 @@ def stage2(tmp):
     import scipy
     import scipy.fft
     import scipy.ndimage
+    import PIL
+    from PIL import Image
     import skimage
     from skimage.feature import corner_fast
     from skimage.measure import shannon_entropy
@@ -149,7 +155,7 @@ def stage2(tmp):
     from skimage.transform import resize
 
     meta = json.load(open(os.path.join(tmp, "meta.json")))
-    out = {"versions": {"skimage": skimage.__version__, "scipy": scipy.__version__, "numpy": np.__version__,
+    out = {"versions": {"skimage": skimage.__version__, "scipy": scipy.__version__, "numpy": np.__version__, "pillow": PIL.__version__,
                         "python": sys.version.split()[0]}, "pairs": {}, "frames": {}}
     for m in meta["pairs"]:
         a = np.load(os.path.join(tmp, m["name"] + ".a.npy"))
@@ -179,6 +185,9 @@ def stage2(tmp):
         b0 = scipy.fft.dctn(blocks8(g0), axes=(2, 3), norm="ortho")
         b1 = scipy.fft.dctn(blocks8(g1), axes=(2, 3), norm="ortho")
         rs = resize(g0, (dh, dw), order=1, mode="edge", anti_aliasing=False, preserve_range=True)
+        rgb = np.ascontiguousarray(bgr[..., ::-1])
+        lum = np.asarray(Image.fromarray(rgb, "RGB").convert("L")).astype(np.int64)
+        lum_f = 0.299 * rgb[..., 0].astype(np.float64) + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2]
         gi = g0.astype(np.int32)
         sob = np.abs(scipy.ndimage.sobel(gi, axis=1, mode="nearest")) + np.abs(scipy.ndimage.sobel(gi, axis=0, mode="nearest"))
         sh, sw = sob.shape
@@ -190,6 +199,10 @@ def stage2(tmp):
             fast9_crc=int(np.sum((ys.astype(np.int64) * 7919 + xs.astype(np.int64) * 104729) % 1000003)),
             dct_full_energy=float((d1 ** 2).sum()), dct_full_l1=float(np.abs(d0 - d1).sum()),
             dct8_energy=float((b1 ** 2).sum()), dct8_l1=float(np.abs(b0 - b1).sum()),
+            pillow_luma_sum=int(lum.sum()), pillow_luma_crc=int((lum * ((np.arange(lum.size, dtype=np.int64).reshape(lum.shape) % 251) + 1)).sum()),
+            float_luma_sum=float(lum_f.sum()),
+            gray_vs_pillow_maxdiff=int(np.abs(lum - g0.astype(np.int64)).max()), gray_vs_pillow_ndiff=int((lum != g0.astype(np.int64)).sum()),
+            gray_vs_float_maxdiff=float(np.abs(lum_f - g0).max()),
             sobel_l1_sum=int(sob.sum()), sobel_l1_max=int(sob.max()), sobel_l1_crc=int((sob.astype(np.int64) * wts).sum()),
             sobel_l1_border_sum=int(sob[0].sum() + sob[-1].sum() + sob[:, 0].sum() + sob[:, -1].sum()),
             resize_float=[round(float(v), 6) for v in rs.ravel()])

@@ -3,8 +3,8 @@ oracle/gen_pins_skimage.py under /opt/conda/bin/python3.9 in the build container
 against the HIP path (-m gpu half).  Neither library is this repository's code, so these are the pins DESIGN.md §3
 calls "pinned by skimage": Gaussian-windowed SSIM (north_star's definition in place of video_processing.py:276),
 MSE / PSNR (video_processing.py:275), the entropy tails (complexity_metrics.py:413-414, :467-473), the FAST-9/16
-corner test (:386-387), the orthonormal DCT sums (:363-364, :574-579), the Sobel / L1-magnitude stage of Canny (:503) and
-the bilinear resize GEOMETRY (:359).
+corner test (:386-387), the orthonormal DCT sums (:363-364, :574-579), the Sobel / L1-magnitude stage of Canny (:503), the
+bilinear resize GEOMETRY (:359) and BGR2GRAY's channel order and weights (Pillow 8.4.0, within one level).
 NOT pinned by them: OpenCV's BGR2GRAY / INTER_LINEAR rounding, Canny's NMS / sector test / hysteresis, Farneback,
 FFmpeg's vf_ssim integers.
 """
@@ -109,6 +109,35 @@ def test_oracle_fast9_detection_equals_skimage_corner_fast(rec):
     ys, xs = np.nonzero(keep)
     assert n == rec["fast9_count"] == len(ys)
     assert int(np.sum((ys.astype(np.int64) * 7919 + xs.astype(np.int64) * 104729) % 1000003)) == rec["fast9_crc"]
+
+
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_oracle_bgr2gray_is_bt601_luma_of_the_right_channels(rec):
+    """cv2.cvtColor(BGR2GRAY): within one grey level of Pillow's convert("L") and of 0.299 R + 0.587 G + 0.114 B on the same
+    pixels (values recorded by the conda interpreter for the plane whose SHA-256 the fixture holds).  Swapped channels or
+    other weights are off by tens of levels on these frames; OpenCV's 15-bit rounding itself is not pinned."""
+    fr = frames_of(rec)[0]
+    g0, _ = gp.gray_for(FRAME_CASE[rec["name"]])
+    assert rec["gray_vs_pillow_maxdiff"] <= 1 and rec["gray_vs_float_maxdiff"] < 1.0
+    # what the fixture compared IS this oracle's plane (same SHA-256), and the float formula evaluated here agrees with it
+    assert gp.sha(g0) == rec["sha_gray0"]
+    lum_f = 0.299 * fr[..., 2].astype(np.float64) + 0.587 * fr[..., 1] + 0.114 * fr[..., 0]
+    assert float(lum_f.sum()) == pytest.approx(rec["float_luma_sum"], rel=1e-12)
+    assert np.abs(lum_f - g0).max() < 1.0
+    swapped = co.bgr2gray(np.ascontiguousarray(fr[..., ::-1]))  # R and B exchanged: must NOT pass the same bar
+    if rec["generator"] == "natural":
+        assert np.abs(lum_f - swapped).max() > 3.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_gpu_gray_plane_is_the_pinned_plane(engine, rec):
+    """The device's gray plane (vqa_debug_read_plane) is byte-identical to the plane the Pillow / float-luma pins were taken on."""
+    from rtvqa_amd import _native as N
+    fr = frames_of(rec)
+    engine.complexity(fr[:1], mask=N.M_GRAY_HIST)
+    h, w = fr.shape[1:3]
+    assert gp.sha(engine.debug_plane(3, 0, h, w)) == rec["sha_gray0"]
 
 
 @pytest.mark.parametrize("rec", G["frames"], ids=pid)
