@@ -212,11 +212,11 @@ def test_canny_count_and_map(engine, name, low, high):
     assert int(rec[0]["edge_count"]) == cnt
 
 
-@pytest.mark.parametrize("w", [4, 5, 7, 8, 63, 64, 65, 255, 256, 257, 258, 259, 260, 261, 511, 512, 513, 514, 515, 516, 517, 770])
+@pytest.mark.parametrize("w", [1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 255, 256, 257, 258, 259, 260, 261, 511, 512, 513, 514, 515, 516, 517, 770])
 def test_canny_strip_and_border_widths(engine, w):
     """k_canny_nms3 works on 256-column strips with a one-column halo group and takes its interior (no realignment)
     path only when a strip's dword windows stay inside the image (x0 + 259 <= w): every width around those seams, the
-    4-column minimum of the dword window (narrower frames take the byte-load kernel), two strips of rows, and
+    4-column minimum of the dword window (frames of 1-3 columns take the LDS-tile kernel k_canny_nms), two strips of rows, and
     thresholds that are negative / swapped / zero."""
     from rtvqa_amd import _native as N
     h = 67
