@@ -312,7 +312,9 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
     constexpr int NS = 12;                  // accumulator ring: 11 live output rows + 1 spare slot, so that R divides the ring
     constexpr int ST = R == 8 ? 3 : 6;      // steps per loop iteration
     constexpr int GR = ST * R;              // rows per loop iteration: a whole number of ring turns
-    constexpr int NB = R == 8 ? 1 : 2;      // LDS row buffers: double (one barrier per step) or, R = 8 probe, single (two)
+    constexpr int NB = R == 8 ? 1 : 2;      // LDS row buffers: R = 8 (shipped) has ONE and two barriers per step (33 KB, 4 waves
+                                            // per SIMD; double-buffered it needs 66 KB, drops to 2 waves and turns latency-bound);
+                                            // the R = 2 / 4 measurement builds double-buffer with one barrier per step
     __shared__ float4 vb[NB][R][QT + 1];    // [step parity][row of the step][column]
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
@@ -355,12 +357,13 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
     };
     uint32_t nr = ld(rres, 0), nd = ld(dres, 0);
 
-    // LDS double buffering: step st stores into buffer st & 1, the buffer the step BEFORE LAST read from; the one barrier
-    // per step orders that.  A loop iteration has an EVEN number of steps (6), so the parity carries across iterations
-    // (R = 8, a measurement build, has 3: there the buffer is (st & 1) ^ gpar with gpar flipping per iteration).
-    // (Round 4's first version had 11 steps per iteration: its last step and the next iteration's first then shared a
-    // buffer with no barrier between read and overwrite - a race that every parity test survived and that the bench's
-    // serial-vs-timed comparison caught; test_results_are_bit_identical_run_to_run is its permanent test.)
+    // LDS row buffers.  NB = 1 (shipped): a barrier before the step's stores (the previous step's readers are done) and one
+    // before its reads.  NB = 2: step st stores into buffer st & 1 - the one the step BEFORE LAST read from - and one
+    // barrier per step orders that, PROVIDED the parity carries across loop iterations: an iteration must have an even
+    // number of steps, or flip gpar.  (Round 4's first kernel had 11 steps per iteration and no flip: its last step and
+    // the next iteration's first shared a buffer with no barrier between read and overwrite - a race that every parity
+    // test survived and that the bench's serial-vs-timed comparison caught; test_results_are_bit_identical_run_to_run
+    // is its permanent test.)
     int gpar = 0;
     // vertical pass of one input row; p = r mod NS (static after unrolling).  Input row r is tap k of output row r - k,
     // kept in ring slot (r - k) mod NS.  emit: store the completed output row r - 10 into vb[sp][slot][t]
