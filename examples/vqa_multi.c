@@ -17,7 +17,11 @@
  * Exit code 0 = every call succeeded on every device and the reduced frame count equals devices x frames.
  * With ONE device this runs everywhere the library runs (tests/test_abi.py does that on the GPU box); with several it
  * needs a multi-GPU node, which no run of this repository has had yet - it is the last mile that could be prepared
- * without the hardware. */
+ * without the hardware.
+ * Rehearsal: VQA_MULTI_REHEARSAL_DEVICE=<d> puts EVERY worker on device d (so `devices` may exceed the device count):
+ * the host threads, contexts, streams and the communicator's bookkeeping then run for real on a one-GPU box.  RCCL
+ * itself refuses two ranks on one device, so the rehearsal needs the LAB build of the library (-DVQA_TEST_SEAMS) with
+ * VQA_COMM_FAKE_RCCL=1; against the shipped library vqa_comm_create reports the duplicate device and the program fails. */
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -28,7 +32,7 @@
 #include "vqa.h"
 
 typedef struct worker {
-    int device, n, h, w, passes;
+    int device, stream_id, n, h, w, passes;
     vqa_ctx *ctx;
     int rc;
     char err[256];
@@ -90,7 +94,7 @@ static void *run_device(void *arg)
     WCHECK(vqa_alloc_device(wk->ctx, fb * (size_t)(n + 1), &dref));
     WCHECK(vqa_alloc_device(wk->ctx, fb * (size_t)(n + 1), &ddist));
     for (int t = 0; t <= n; t++) { /* the stream becomes resident in HBM frame by frame through one pinned buffer */
-        synth_frame(href, hdist, h, w, t, (unsigned)wk->device);
+        synth_frame(href, hdist, h, w, t, (unsigned)wk->stream_id);
         WCHECK(vqa_copy_h2d(wk->ctx, (uint8_t *)dref + fb * (size_t)t, href, fb));
         WCHECK(vqa_copy_h2d(wk->ctx, (uint8_t *)ddist + fb * (size_t)t, hdist, fb));
         WCHECK(vqa_sync(wk->ctx));
@@ -146,16 +150,19 @@ int main(int argc, char **argv)
         fprintf(stderr, "vqa_device_count -> %s\n", vqa_strerror(VQA_ERR_NO_DEVICE));
         return 2;
     }
+    const char *reh = getenv("VQA_MULTI_REHEARSAL_DEVICE");
+    const int reh_dev = reh ? atoi(reh) : -1;
+    if (reh && (reh_dev < 0 || reh_dev >= avail)) { fprintf(stderr, "VQA_MULTI_REHEARSAL_DEVICE out of range\n"); return 2; }
     int nd = argc > 1 ? atoi(argv[1]) : avail;
     const int n = argc > 2 ? atoi(argv[2]) : 16, passes = argc > 3 ? atoi(argv[3]) : 3;
     const int h = argc > 5 ? atoi(argv[4]) : 2160, w = argc > 5 ? atoi(argv[5]) : 3840;
-    if (nd <= 0 || nd > avail) nd = avail;
+    if (nd <= 0 || (!reh && nd > avail)) nd = avail;
     if (nd > 64 || n <= 0 || passes <= 0 || h < 16 || w < 16) { fprintf(stderr, "bad arguments\n"); return 2; }
     worker wk[64];
     pthread_t th[64];
     memset(wk, 0, sizeof wk);
     for (int d = 0; d < nd; d++) {
-        wk[d].device = d; wk[d].n = n; wk[d].h = h; wk[d].w = w; wk[d].passes = passes;
+        wk[d].device = reh ? reh_dev : d; wk[d].stream_id = d; wk[d].n = n; wk[d].h = h; wk[d].w = w; wk[d].passes = passes;
         if (pthread_create(&th[d], NULL, run_device, &wk[d]) != 0) { fprintf(stderr, "pthread_create failed\n"); return 2; }
     }
     int bad = 0;
@@ -173,7 +180,7 @@ int main(int argc, char **argv)
             vals[d][0] = wk[d].ssim_sum; vals[d][1] = wk[d].dct_sum; vals[d][2] = (double)n;
             const double fps = (double)n * passes / wk[d].seconds;
             total_fps += fps;
-            printf("device %d: %d x %dx%d frames x %d passes  %.1f frames/s  mean SSIM %.6f  edges/frame %.0f\n", d, n, w, h, passes,
+            printf("worker %d on device %d: %d x %dx%d frames x %d passes  %.1f frames/s  mean SSIM %.6f  edges/frame %.0f\n", d, wk[d].device, n, w, h, passes,
                    fps, wk[d].ssim_sum / n, (double)wk[d].edges / n);
         }
         vqa_comm *comm = NULL;

@@ -127,13 +127,13 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b|#include\s+\"[^\"]*oracle", txt, flags=re.M), f
 
 
-def _build_demo(tmp_path, name="vqa_demo"):
+def _build_demo(tmp_path, name="vqa_demo", lab=False):
     import subprocess
-    exe = str(tmp_path / name)
-    libdir = os.path.join(REPO, "real-time-video-quality-analysis_amd", "csrc")
+    exe = str(tmp_path / (name + ("_lab" if lab else "")))
+    libdir = os.path.join(REPO, "real-time-video-quality-analysis_amd", "csrc", *(["lab"] if lab else []))
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-pthread", "-I", os.path.join(REPO, "include"), "-o", exe,
-                           os.path.join(REPO, "examples", name + ".c"), "-L", libdir, "-lvqa_hip",
-                           "-Wl,-rpath," + libdir, "-lm"])
+                           os.path.join(REPO, "examples", name + ".c"), "-L", libdir,
+                           "-l:libvqa_hip_lab.so" if lab else "-lvqa_hip", "-Wl,-rpath," + libdir, "-lm"])
     return exe
 
 
@@ -171,6 +171,25 @@ def test_multi_device_c_host_runs_with_the_devices_present(tmp_path):
     r = subprocess.run([_build_demo(tmp_path, "vqa_multi"), "0", "6", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "vqa_multi ok" in r.stdout, r.stdout + r.stderr
     assert re.search(r"all-reduce over \d+ device\(s\): \d+ frames", r.stdout) or "RCCL not installed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_multi_device_c_host_rehearsal_three_workers_on_one_gpu(tmp_path):
+    """The multi-device host for real, minus the second device: VQA_MULTI_REHEARSAL_DEVICE=0 puts three workers (three
+    host threads, three contexts, three streams running concurrently) on the one GPU; linked against the LAB build, whose
+    RCCL stand-in (VQA_COMM_FAKE_RCCL=1) lets vqa_comm_create take three contexts of one device.  The reduced frame count
+    must be 3 x frames and every worker's self-checks (Parseval, hysteresis bound) must hold.  Against the SHIPPED library
+    the same rehearsal must fail at vqa_comm_create: it has no stand-in and real RCCL takes one rank per device."""
+    import subprocess
+    env = dict(os.environ, VQA_MULTI_REHEARSAL_DEVICE="0", VQA_COMM_FAKE_RCCL="1")
+    r = subprocess.run([_build_demo(tmp_path, "vqa_multi", lab=True), "3", "8", "2", "1080", "1920"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "vqa_multi ok" in r.stdout, r.stdout + r.stderr
+    assert "all-reduce over 3 device(s): 24 frames" in r.stdout, r.stdout
+    assert len(re.findall(r"^worker \d on device 0:", r.stdout, flags=re.M)) == 3
+    r = subprocess.run([_build_demo(tmp_path, "vqa_multi"), "3", "2", "1", "270", "480"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 1 and "two contexts on device 0" in r.stderr, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
