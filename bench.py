@@ -678,6 +678,19 @@ def main():
                 # expansion 24 B + 3 x (product rebuild 68 B + box/solve 28 B) = 312 B, x 4/3 for the pyramid, + ~25 B of blur
                 "farneback(pyramid)": 440 * P * B,
             }
+            def _smooth(n):  # the library's rule (k_dct_fft.hip, dct_fft_factor): even, 128..4096, prime factors 2, 3, 5
+                if n < 128 or n > 4096 or n % 2:
+                    return False
+                for q in (2, 3, 5):
+                    while n % q == 0:
+                        n //= q
+                return n == 1
+            mfma_flops = {}
+            if _smooth(h) and _smooth(w) and h <= 2560:
+                # FFT-based row / column passes: both u8 planes read (2P), two float planes written (8P) and read back (8P)
+                alg_bytes["k_dct_full"] = 18 * P * B
+            else:
+                mfma_flops = {"k_dct_full": 2 * 2.0 * (w * w * h + h * h * w) * B}  # energy + temporal, 2 dense products each
             kernels = {}
             for name, (ms, cnt) in prof.items():
                 per = ms / cnt
@@ -698,7 +711,6 @@ def main():
                 if name in kernels:
                     tf = 2.0 * fma / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
                     kernels[name].update({"fma": fma, "TFLOPps": round(tf, 1), "frac_fp32": round(tf / 157.3, 4)})
-            mfma_flops = {"k_dct_full(gemm_nt x4)": 2 * 2.0 * (w * w * h + h * h * w) * B}  # energy + temporal, 2 products each
             for name, fl in mfma_flops.items():
                 if name in kernels:
                     tf = fl / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12

@@ -218,7 +218,7 @@ enum vqa_kernel_id {
     VQA_K_GRAY_HIST = 0, /* BGR->gray + histograms, native resolution   */
     VQA_K_RESIZE = 1,    /* cv2.resize gather + gray + histograms       */
     VQA_K_DCT8 = 2,      /* 8x8 DCT energy + temporal L1                */
-    VQA_K_DCT_FULL = 3,  /* full-frame DCT (4 launches per batch)       */
+    VQA_K_DCT_FULL = 3,  /* full-frame DCT: FFT row + column passes, or (sizes that do not factor into 2,3,5) 4 dense products */
     VQA_K_CANNY_NMS = 4,
     VQA_K_CANNY_HYST = 5,
     VQA_K_SAD = 6,

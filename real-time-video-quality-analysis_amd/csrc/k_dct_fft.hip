@@ -1,0 +1,281 @@
+// k_dct_fft.hip — the reference's full-frame cv2.dct metrics at native resolution, the fast way.
+//
+// Reference functions replaced (complexity_metrics.py):
+//   :363-364  np.sum(cv2.dct(np.float32(gray)) ** 2)                      -> dct_energy
+//   :574-579  np.sum(np.abs(cv2.dct(prev) - cv2.dct(curr)))  (full frame) -> temporal_dct_l1
+//
+// "full-frame DCT via mixed-radix (1080 = 2^3 3^3 5, 1920 = 2^7 3 5) row/column passes".
+// k_dct_full.hip computes Y = C_h X C_w^T as two dense products (12.4 GFLOP per 1080p frame pair, on the matrix
+// cores); this file computes the same orthonormal 2-D DCT-II in O(P log P): every 1-D DCT is ONE complex FFT of the
+// same length (Makhoul's reordering v[n] = x[2n], v[N-1-n] = x[2n+1]; C[k] = Re(e^{-i pi k / 2N} V[k])), and the two
+// real sequences the metrics need - the current plane for the energy, prev - curr for the temporal L1 (linearity:
+// dct(prev) - dct(curr) = dct(prev - curr)) - ride in the real and imaginary parts of that one FFT
+// (A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i).
+//
+//   k_dct_fft_rows: one workgroup transforms rows: u8 samples -> LDS (centred at 128: the constant's DC term is put
+//                   back analytically, which keeps the FFT's rounding noise relative to the texture, not to the
+//                   offset) -> Stockham autosort passes of radix 8 / 4 / 2 / 3 / 5 in LDS -> two float planes.
+//   k_dct_fft_cols: one workgroup transforms a tile of adjacent columns of both planes the same way and reduces
+//                   sum Ya^2 and sum |Yb| on the fly: the 2-D coefficients are never written.
+// Lengths must be even and factor into 2, 3, 5 (1080p, 2160p, 720p, 480p ... do); other sizes take k_dct_full.hip.
+// No dense contraction is left, so nothing here uses MFMA.  Roofline: HBM (P bytes in + 8P out, 8P in per frame);
+// measured at 1080p, 64 frames: rows 1.10 ms + columns 1.96 ms against 15.1 ms for the matrix-core version - both passes are
+// bound by the barriers between their short radix passes (latency / occupancy), not by HBM.
+#include "vqa_dev.hpp"
+#include "vqa_kernels.hpp"
+
+namespace vqa {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mulmi(float2 a) { return make_float2(a.y, -a.x); } // a * (-i)
+
+// forward DFTs of length R (kernel e^{-2 pi i / R}), in place
+template <int R>
+__device__ __forceinline__ void dft(float2 *v);
+template <>
+__device__ __forceinline__ void dft<2>(float2 *v)
+{
+    const float2 a = v[0], b = v[1];
+    v[0] = cadd(a, b); v[1] = csub(a, b);
+}
+template <>
+__device__ __forceinline__ void dft<3>(float2 *v)
+{
+    const float2 s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    const float2 m = make_float2(v[0].x - 0.5f * s.x, v[0].y - 0.5f * s.y);
+    const float2 r = make_float2(0.86602540378443865f * d.y, -0.86602540378443865f * d.x); // (-i sqrt3/2) d
+    v[0] = cadd(v[0], s); v[1] = cadd(m, r); v[2] = csub(m, r);
+}
+template <>
+__device__ __forceinline__ void dft<4>(float2 *v)
+{
+    const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = mulmi(csub(v[1], v[3]));
+    v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+}
+template <>
+__device__ __forceinline__ void dft<8>(float2 *v)
+{
+    // two radix-4 transforms of the even / odd samples, combined with the eighth roots of unity
+    float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    dft<4>(e);
+    dft<4>(o);
+    constexpr float r = 0.70710678118654752f;
+    const float2 o1 = make_float2(r * (o[1].x + o[1].y), r * (o[1].y - o[1].x));   // o1 (1 - i) / sqrt2
+    const float2 o2 = mulmi(o[2]);                                                 // o2 (-i)
+    const float2 o3 = make_float2(r * (o[3].y - o[3].x), -r * (o[3].x + o[3].y));  // o3 (-1 - i) / sqrt2
+    v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+    v[1] = cadd(e[1], o1);   v[5] = csub(e[1], o1);
+    v[2] = cadd(e[2], o2);   v[6] = csub(e[2], o2);
+    v[3] = cadd(e[3], o3);   v[7] = csub(e[3], o3);
+}
+template <>
+__device__ __forceinline__ void dft<5>(float2 *v)
+{
+    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f, s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const float2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+    const float2 m1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+    const float2 m2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+    const float2 n1 = mulmi(make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y));
+    const float2 n2 = mulmi(make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y));
+    v[0] = make_float2(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+    v[1] = cadd(m1, n1); v[4] = csub(m1, n1); v[2] = cadd(m2, n2); v[3] = csub(m2, n2);
+}
+
+// One Stockham autosort pass of radix R over `cols` independent sequences of length N stored back to back:
+// butterfly j of a sequence reads in[j + t N/R], twiddles input t by e^{-2 pi i t k / (Ns R)} (k = j mod Ns, Ns = the
+// product of the radices already applied) and writes out[(j - k) R + k + t Ns].  tw[m] = e^{-2 pi i m / N}.
+template <int R>
+__device__ __forceinline__ void fft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
+                                         int N, int Ns, int cols, int tid, int nthreads)
+{
+    const int M = N / R, tstep = N / (Ns * R);
+    for (int i = tid; i < cols * M; i += nthreads) {
+        const int c = i / M, j = i - c * M;
+        const int k = j % Ns;
+        const float2 *src = in + c * N + j;
+        float2 v[R];
+        v[0] = src[0];
+#pragma unroll
+        for (int t = 1; t < R; t++) v[t] = cmul(src[t * M], tw[t * k * tstep]);
+        dft<R>(v);
+        float2 *dst = out + c * N + (j - k) * R + k;
+#pragma unroll
+        for (int t = 0; t < R; t++) dst[t * Ns] = v[t];
+    }
+}
+
+// all passes of a plan; returns the buffer that holds the (naturally ordered) spectrum
+__device__ __forceinline__ float2 *fft_run(const dct_fft_plan &P, float2 *b0, float2 *b1, const float2 *tw, int cols, int tid,
+                                           int nthreads)
+{
+    float2 *in = b0, *out = b1;
+    int Ns = 1;
+    for (int p = 0; p < P.npass; p++) {
+        const int R = P.radix[p];
+        if (R == 8) fft_pass<8>(in, out, tw, P.n, Ns, cols, tid, nthreads);
+        else if (R == 4) fft_pass<4>(in, out, tw, P.n, Ns, cols, tid, nthreads);
+        else if (R == 2) fft_pass<2>(in, out, tw, P.n, Ns, cols, tid, nthreads);
+        else if (R == 3) fft_pass<3>(in, out, tw, P.n, Ns, cols, tid, nthreads);
+        else fft_pass<5>(in, out, tw, P.n, Ns, cols, tid, nthreads);
+        __syncthreads();
+        float2 *t = in; in = out; out = t;
+        Ns *= R;
+    }
+    return in;
+}
+
+// Makhoul's input order: even samples ascending, odd samples descending
+__device__ __forceinline__ int makhoul_pos(int n, int N) { return (n & 1) ? N - 1 - (n >> 1) : (n >> 1); }
+
+// the two real spectra packed in Z, then the DCT-II coefficients of both: post[k] = s_k (cos, sin)(pi k / 2N)
+__device__ __forceinline__ float2 dct_from_fft(const float2 *Z, int k, int N, float2 post)
+{
+    const float2 zk = Z[k], zn = Z[k ? N - k : 0];
+    const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y); // A = (Z[k] + conj Z[N-k]) / 2
+    const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x); // B = (Z[k] - conj Z[N-k]) / 2i
+    return make_float2(post.x * ax + post.y * ay, post.x * bx + post.y * by);
+}
+
+// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = (2 + TWL) * w * 8 bytes
+template <bool TWL>
+__global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride, int h,
+                                                      int w, dct_fft_plan P, float *__restrict__ Ra, float *__restrict__ Rb,
+                                                      int rows_per_wg)
+{
+    extern __shared__ float2 lds_fft[];
+    float2 *b0 = lds_fft, *b1 = lds_fft + w;
+    const float2 *tw = P.tw;
+    const int tid = threadIdx.x, f = blockIdx.y;
+    if (TWL) {
+        float2 *twl = lds_fft + 2 * w;
+        for (int i = tid; i < w; i += 256) twl[i] = P.tw[i];
+        tw = twl;
+    }
+    const uint8_t *cur = planes + (int64_t)(f + 1) * plane_stride, *prev = planes + (int64_t)f * plane_stride;
+    const float dc = 128.f * sqrtf((float)w); // row-DCT of the constant that was subtracted
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
+    for (int r = r0; r < r1; r++) {
+        __syncthreads(); // the previous row's readers are done (and the twiddle table is complete)
+        for (int n = tid; n < w; n += 256) {
+            const int cv = cur[(int64_t)r * pitch + n], pv = prev[(int64_t)r * pitch + n];
+            b0[makhoul_pos(n, w)] = make_float2((float)(cv - 128), (float)(pv - cv));
+        }
+        __syncthreads();
+        const float2 *Z = fft_run(P, b0, b1, tw, 1, tid, 256);
+        float *oa = Ra + ((int64_t)f * h + r) * w, *ob = Rb + ((int64_t)f * h + r) * w;
+        for (int k = tid; k < w; k += 256) {
+            const float2 c = dct_from_fft(Z, k, w, P.post[k]);
+            oa[k] = k ? c.x : c.x + dc;
+            ob[k] = c.y;
+        }
+    }
+}
+
+// grid = (ceil(w / ct), n_frames), block = 256, dynamic LDS = (2 ct + TWL) * h * 8 bytes
+template <bool TWL>
+__global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ Ra, const float *__restrict__ Rb, int h, int w,
+                                                      dct_fft_plan P, int ct, double *__restrict__ pe, double *__restrict__ pt)
+{
+    extern __shared__ float2 lds_fft[];
+    __shared__ double red[4];
+    float2 *b0 = lds_fft, *b1 = lds_fft + ct * h;
+    const float2 *tw = P.tw;
+    const int tid = threadIdx.x, f = blockIdx.y;
+    if (TWL) {
+        float2 *twl = lds_fft + 2 * ct * h;
+        for (int i = tid; i < h; i += 256) twl[i] = P.tw[i];
+        tw = twl;
+    }
+    // XCD-aware tile order (workgroup ids go round-robin over the 8 XCDs): XCD c takes a contiguous range of column tiles,
+    // so the neighbours that share 64-byte sectors of a row meet in ONE L2
+    const int per = ((int)gridDim.x + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    const int ntiles = (w + ct - 1) / ct;
+    if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles) return;
+    const int x0 = tile * ct, nc = min(ct, w - x0);
+    const float *pa = Ra + (int64_t)f * h * w + x0, *pb = Rb + (int64_t)f * h * w + x0;
+    for (int i = tid; i < nc * h; i += 256) {
+        const int m = i / nc, c = i - m * nc;
+        b0[c * h + makhoul_pos(m, h)] = make_float2(pa[(int64_t)m * w + c], pb[(int64_t)m * w + c]);
+    }
+    __syncthreads();
+    const float2 *Z = fft_run(P, b0, b1, tw, nc, tid, 256);
+    double e = 0, t = 0;
+    for (int i = tid; i < nc * h; i += 256) {
+        const int c = i / h, k = i - c * h;
+        const float2 y = dct_from_fft(Z + c * h, k, h, P.post[k]);
+        e += (double)y.x * (double)y.x;
+        t += (double)fabsf(y.y);
+    }
+    const double es = block_sum(e, red);
+    const double ts = block_sum(t, red);
+    if (tid == 0) {
+        pe[(int64_t)f * ntiles + tile] = es;
+        pt[(int64_t)f * ntiles + tile] = ts;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+// radix-8 passes first, then 4, 2, 3, 5; false if n is odd, has another prime factor, or is too short / too long to pay
+bool dct_fft_factor(int n, int radix[DCT_FFT_MAX_PASSES], int *npass)
+{
+    if (n < 128 || n > 4096 || (n & 1)) return false;
+    int m = n, np = 0;
+    while (m % 8 == 0 && np < DCT_FFT_MAX_PASSES) { radix[np++] = 8; m /= 8; }
+    while (m % 4 == 0 && np < DCT_FFT_MAX_PASSES) { radix[np++] = 4; m /= 4; }
+    static const int primes[3] = {2, 3, 5};
+    for (int pi = 0; pi < 3; pi++)
+        while (m % primes[pi] == 0 && np < DCT_FFT_MAX_PASSES) { radix[np++] = primes[pi]; m /= primes[pi]; }
+    if (m != 1) return false;
+    *npass = np;
+    return true;
+}
+
+// columns per workgroup of the column pass: as many as 64 KiB of LDS hold (two buffers per column + the twiddle table):
+// 3 at 1080 rows.  Measured at 1080p, 64 frames: 3 columns (60 KB, two workgroups per CU) 1.96 ms; 8 columns with the
+// 144 KB a gfx950 workgroup may ask for (32-byte row segments, ONE workgroup per CU) 2.49 ms - the pass is bound by
+// the barriers between its short radix passes, i.e. by occupancy, not by how well its loads coalesce.
+static int dct_fft_ct(int h)
+{
+    int ct = (64 * 1024 - 64 - h * 8) / (2 * h * 8);
+    return ct < 1 ? 1 : (ct > 8 ? 8 : ct);
+}
+
+// both sides factor, and a column (two buffers + the twiddle table) fits the 64 KiB every runtime grants
+bool dct_fft_supported(int h, int w)
+{
+    int rx[DCT_FFT_MAX_PASSES], np;
+    return h <= 2560 && dct_fft_factor(h, rx, &np) && dct_fft_factor(w, rx, &np);
+}
+
+int dct_fft_tiles(int h, int w)
+{
+    const int ct = dct_fft_ct(h);
+    return (w + ct - 1) / ct;
+}
+
+// planes: slot 0 = frame before the batch, slot i+1 = batch frame i (u8, pitch).  scratch: 2 * n * h * w floats.
+// pe / pt: n * dct_fft_tiles(h, w) doubles each.  The finalize kernel is k_dct_full.hip's.
+void launch_dct_full_fft(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
+                         const dct_fft_plan &pw_, const dct_fft_plan &ph_, float *scratch, double *pe, double *pt, bool energy,
+                         bool temporal, bool first_has_prev, vqa_frame_metrics *res)
+{
+    if (n <= 0 || (!energy && !temporal)) return;
+    float *Ra = scratch, *Rb = scratch + (int64_t)n * h * w;
+    const bool twl_w = 3 * w * 8 <= 64 * 1024 - 64;
+    const int rpw = 8;
+    const dim3 gr((h + rpw - 1) / rpw, n);
+    if (twl_w)
+        hipLaunchKernelGGL(k_dct_fft_rows<true>, gr, dim3(256), (size_t)3 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb, rpw);
+    else
+        hipLaunchKernelGGL(k_dct_fft_rows<false>, gr, dim3(256), (size_t)2 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb, rpw);
+    const int ct = dct_fft_ct(h);
+    const int tiles = (w + ct - 1) / ct;
+    const dim3 gc((tiles + 7) / 8 * 8, n);
+    hipLaunchKernelGGL(k_dct_fft_cols<true>, gc, dim3(256), (size_t)(2 * ct + 1) * h * 8, st, Ra, Rb, h, w, ph_, ct, pe, pt);
+    launch_dct_full_finalize(st, pe, pt, tiles, n, res, energy, temporal, first_has_prev);
+}
+
+} // namespace vqa

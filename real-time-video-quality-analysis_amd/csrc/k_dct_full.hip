@@ -6,6 +6,8 @@
 //     Tt = C_w . X^T         (w x h)      X = gray, or prev - curr (linearity)
 //     Yt = Tt . C_h^T        (w x h)      reduced on the fly: sum Y^2 or sum |Y|
 //
+// Planes whose sides are even and factor into 2, 3, 5 (1080p, 2160p, 720p ...) take k_dct_fft.hip instead (round 4:
+// the same metrics in O(P log P)); this file serves every other size.
 // This is the PARITY mode: O(P (H + W)) flops, not the throughput path (the 8x8 block kernel is).  At
 // 64x64 the whole transform is 1 MFLOP per frame and runs on the vector ALUs (k_gemm_nt).  At native
 // resolution (1080p = 12.4 GFLOP per frame pair) the two products are the one truly
@@ -189,23 +191,32 @@ __global__ __launch_bounds__(256) void k_gemm_nt_mfma(const float *__restrict__ 
     }
 }
 
-__global__ void k_full_finalize(const double *__restrict__ pe, const double *__restrict__ pt, int tiles, int n,
-                                vqa_frame_metrics *__restrict__ res, int write_energy, int write_temporal,
-                                int first_has_prev)
+// one wave per frame: lane i adds partials i, i + 64, ... in double, then a fixed-order shuffle tree (bit-reproducible).
+// (A thread per frame walked up to 640 partials serially: 0.14 ms per 64 frames behind the FFT passes' 3 ms.)
+__global__ __launch_bounds__(64) void k_full_finalize(const double *__restrict__ pe, const double *__restrict__ pt, int tiles, int n,
+                                                      vqa_frame_metrics *__restrict__ res, int write_energy, int write_temporal,
+                                                      int first_has_prev)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x;
     if (f >= n) return;
-    if (write_energy) {
-        double e = 0;
-        for (int i = 0; i < tiles; i++) e += pe[(int64_t)f * tiles + i];
-        res[f].dct_energy = e;
+    double e = 0, t = 0;
+    for (int i = threadIdx.x; i < tiles; i += 64) {
+        if (write_energy) e += pe[(int64_t)f * tiles + i];
+        if (write_temporal) t += pt[(int64_t)f * tiles + i];
     }
-    if (write_temporal) {
-        double t = 0;
-        if (f > 0 || first_has_prev)
-            for (int i = 0; i < tiles; i++) t += pt[(int64_t)f * tiles + i];
-        res[f].temporal_dct_l1 = t;
+    e = wave_sum(e);
+    t = wave_sum(t);
+    if (threadIdx.x == 0) {
+        if (write_energy) res[f].dct_energy = e;
+        if (write_temporal) res[f].temporal_dct_l1 = (f > 0 || first_has_prev) ? t : 0.0;
     }
+}
+
+void launch_dct_full_finalize(hipStream_t st, const double *pe, const double *pt, int tiles, int n, vqa_frame_metrics *res,
+                              bool energy, bool temporal, bool first_has_prev)
+{
+    hipLaunchKernelGGL(k_full_finalize, dim3(n), dim3(64), 0, st, pe, pt, tiles, n, res, (int)energy, (int)temporal,
+                       (int)first_has_prev);
 }
 
 // planes: slot 0 = frame before the batch, slot i+1 = batch frame i (u8, pitch).
@@ -244,8 +255,7 @@ void launch_dct_full(hipStream_t st, const uint8_t *planes, int pitch, int64_t p
     }
 #undef BOTH
 #undef GEMM
-    hipLaunchKernelGGL(k_full_finalize, dim3((n + 63) / 64), dim3(64), 0, st, pe, pt, tiles, n, res, (int)energy,
-                       (int)temporal, (int)first_has_prev);
+    launch_dct_full_finalize(st, pe, pt, tiles, n, res, energy, temporal, first_has_prev);
 }
 
 } // namespace vqa

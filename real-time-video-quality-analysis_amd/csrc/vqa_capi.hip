@@ -59,6 +59,7 @@ struct vqa_ctx {
     std::map<std::tuple<int, int, int, int>, resize_tabs> tabs;
     std::map<std::tuple<int, int, int, int>, fb_resize_tabs> fb_tabs;
     std::map<int, float *> dct_mats;
+    std::map<int, dct_fft_plan> fft_plans;  // k_dct_fft.hip: twiddle / post-twiddle tables per transform length
     dbuf fb_tmp, fb_blur, fb_img, fb_R, fb_M, fb_flow0, fb_flow1, fb_part;
 
     // pending work
@@ -237,6 +238,33 @@ static int get_dct_matrix(vqa_ctx *c, int n, float **out)
     HIPCHK(c, hipMemcpy(d, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice));
     c->dct_mats[n] = d;
     *out = d;
+    return VQA_OK;
+}
+
+// k_dct_fft.hip's plan for length n (tables formed in double, rounded once); VQA_ERR_UNSUPPORTED if n does not factor
+static int get_fft_plan(vqa_ctx *c, int n, dct_fft_plan *out)
+{
+    auto it = c->fft_plans.find(n);
+    if (it != c->fft_plans.end()) { *out = it->second; return VQA_OK; }
+    dct_fft_plan P;
+    memset(&P, 0, sizeof P);
+    P.n = n;
+    if (!dct_fft_factor(n, P.radix, &P.npass)) return VQA_ERR_UNSUPPORTED;
+    std::vector<float2> tw((size_t)n), post((size_t)n);
+    for (int m = 0; m < n; m++) {
+        const double a = -2.0 * M_PI * (double)m / (double)n;
+        tw[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+        const double s = m == 0 ? std::sqrt(1.0 / n) : std::sqrt(2.0 / n), b = M_PI * (double)m / (2.0 * n);
+        post[m] = make_float2((float)(s * std::cos(b)), (float)(s * std::sin(b)));
+    }
+    float2 *dtw = nullptr, *dpost = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dtw, sizeof(float2) * n));
+    HIPCHK(c, hipMalloc((void **)&dpost, sizeof(float2) * n));
+    HIPCHK(c, hipMemcpy(dtw, tw.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dpost, post.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    P.tw = dtw; P.post = dpost;
+    c->fft_plans[n] = P;
+    *out = P;
     return VQA_OK;
 }
 
@@ -536,6 +564,7 @@ int vqa_destroy(vqa_ctx *c)
         if (kv.second.rows) (void)hipFree(kv.second.rows);
     }
     for (auto &kv : c->dct_mats) (void)hipFree(kv.second);
+    for (auto &kv : c->fft_plans) { (void)hipFree((void *)kv.second.tw); (void)hipFree((void *)kv.second.post); }
     for (auto &t : c->ev_open) { (void)hipEventDestroy(std::get<1>(t)); (void)hipEventDestroy(std::get<2>(t)); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->res_host) (void)hipHostFree(c->res_host);
@@ -757,21 +786,40 @@ static int complexity_submit_body(vqa_ctx *c, const uint8_t *frames, const uint8
             prof_scope ps_(c, VQA_K_DCT8);
             launch_dct8(st, pA, pp, plane_stride, n, ph, pw, want_dct, want_t, has_prev0, (double *)c->partials.p, res);
         } else {
-            float *cw = nullptr, *ch = nullptr;
-            rc = get_dct_matrix(c, pw, &cw);
-            if (rc) return rc;
-            rc = get_dct_matrix(c, ph, &ch);
-            if (rc) return rc;
-            const size_t tiles = (size_t)((ph + 15) / 16) * ((pw + 15) / 16);
-            rc = ensure(c, c->dct_scratch, sizeof(float) * (size_t)ph * pw * n);
-            if (rc) return rc;
-            rc = ensure(c, c->dct_pe, sizeof(double) * tiles * n);
-            if (rc) return rc;
-            rc = ensure(c, c->dct_pt, sizeof(double) * tiles * n);
-            if (rc) return rc;
-            prof_scope ps_(c, VQA_K_DCT_FULL);
-            launch_dct_full(st, pA, pp, plane_stride, n, ph, pw, cw, ch, (float *)c->dct_scratch.p,
-                            (double *)c->dct_pe.p, (double *)c->dct_pt.p, want_dct, want_t, has_prev0, res);
+            if (dct_fft_supported(ph, pw)) {
+                // both sides factor into 2, 3, 5: FFT-based row / column passes (k_dct_fft.hip)
+                dct_fft_plan Pw, Ph;
+                rc = get_fft_plan(c, pw, &Pw);
+                if (rc) return rc;
+                rc = get_fft_plan(c, ph, &Ph);
+                if (rc) return rc;
+                const size_t tiles = (size_t)dct_fft_tiles(ph, pw);
+                rc = ensure(c, c->dct_scratch, sizeof(float) * 2 * (size_t)ph * pw * n);
+                if (rc) return rc;
+                rc = ensure(c, c->dct_pe, sizeof(double) * tiles * n);
+                if (rc) return rc;
+                rc = ensure(c, c->dct_pt, sizeof(double) * tiles * n);
+                if (rc) return rc;
+                prof_scope ps_(c, VQA_K_DCT_FULL);
+                launch_dct_full_fft(st, pA, pp, plane_stride, n, ph, pw, Pw, Ph, (float *)c->dct_scratch.p, (double *)c->dct_pe.p,
+                                    (double *)c->dct_pt.p, want_dct, want_t, has_prev0, res);
+            } else {
+                float *cw = nullptr, *ch = nullptr;
+                rc = get_dct_matrix(c, pw, &cw);
+                if (rc) return rc;
+                rc = get_dct_matrix(c, ph, &ch);
+                if (rc) return rc;
+                const size_t tiles = (size_t)((ph + 15) / 16) * ((pw + 15) / 16);
+                rc = ensure(c, c->dct_scratch, sizeof(float) * (size_t)ph * pw * n);
+                if (rc) return rc;
+                rc = ensure(c, c->dct_pe, sizeof(double) * tiles * n);
+                if (rc) return rc;
+                rc = ensure(c, c->dct_pt, sizeof(double) * tiles * n);
+                if (rc) return rc;
+                prof_scope ps_(c, VQA_K_DCT_FULL);
+                launch_dct_full(st, pA, pp, plane_stride, n, ph, pw, cw, ch, (float *)c->dct_scratch.p,
+                                (double *)c->dct_pe.p, (double *)c->dct_pt.p, want_dct, want_t, has_prev0, res);
+            }
         }
     }
 
@@ -1067,7 +1115,7 @@ int vqa_profile_read(vqa_ctx *c, int id, double *total_ms, int64_t *launches, in
 
 const char *vqa_kernel_name(int id)
 {
-    static const char *names[VQA_K_COUNT] = {"k_bgr2gray_hist", "k_resize_planes", "k_dct8", "k_dct_full(gemm_nt x4)",
+    static const char *names[VQA_K_COUNT] = {"k_bgr2gray_hist", "k_resize_planes", "k_dct8", "k_dct_full",
                                              "k_canny_nms", "k_canny_hyst", "k_block_sad", "k_ssim_gauss",
                                              "k_ssim_ffmpeg", "k_orb64", "farneback(pyramid)"};
     return (id >= 0 && id < VQA_K_COUNT) ? names[id] : "?";

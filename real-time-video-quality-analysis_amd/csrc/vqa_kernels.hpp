@@ -53,6 +53,24 @@ void launch_dct_full(hipStream_t st, const uint8_t *planes, int pitch, int64_t p
                      const float *cw, const float *ch, float *scratch, double *pe, double *pt, bool energy,
                      bool temporal, bool first_has_prev, vqa_frame_metrics *res);
 
+void launch_dct_full_finalize(hipStream_t st, const double *pe, const double *pt, int tiles, int n, vqa_frame_metrics *res,
+                              bool energy, bool temporal, bool first_has_prev);
+
+// k_dct_fft.hip: the same full-frame metrics through FFT-based row / column passes (lengths that factor into 2, 3, 5)
+constexpr int DCT_FFT_MAX_PASSES = 12;
+struct dct_fft_plan {            // one per transform length
+    int n, npass;
+    int radix[DCT_FFT_MAX_PASSES];
+    const float2 *tw;            // device: tw[m] = e^{-2 pi i m / n}, m < n
+    const float2 *post;          // device: post[k] = s_k (cos, sin)(pi k / 2n), s_0 = sqrt(1/n), s_k = sqrt(2/n)
+};
+bool dct_fft_factor(int n, int radix[DCT_FFT_MAX_PASSES], int *npass);
+bool dct_fft_supported(int h, int w); // the plane takes the FFT passes (else k_dct_full.hip's dense products)
+int dct_fft_tiles(int h, int w); // partial sums per frame the column pass writes (sizes pe / pt)
+void launch_dct_full_fft(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
+                         const dct_fft_plan &plan_w, const dct_fft_plan &plan_h, float *scratch, double *pe, double *pt,
+                         bool energy, bool temporal, bool first_has_prev, vqa_frame_metrics *res);
+
 // k_canny.hip
 struct canny_geom {
     int tiles_x, tiles_y;

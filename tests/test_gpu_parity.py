@@ -135,13 +135,15 @@ def test_dct8_constant_frames_known_answer(engine):
     assert rec[0]["temporal_dct_l1"] == 0.0
 
 
-def test_dct_full_frame_1080p_native_vs_scipy(engine):
-    """N1: the reference's full-frame temporal DCT at NATIVE 1080x1920 (complexity_metrics.py:363-364, :574-579) on the
-    fp32 MFMA path - 128x128 tiles with a ragged edge (1080 % 128 != 0), the prefetch tail and the |.| reduction.
-    Checker: scipy.fft.dctn(norm="ortho") in float64 (the C oracle's O(N^3) loop is too slow at this size)."""
+@pytest.mark.parametrize("h,w", [(1080, 1920), (1078, 1918), (720, 1280)])
+def test_dct_full_frame_1080p_native_vs_scipy(engine, h, w):
+    """N1: the reference's full-frame temporal DCT at NATIVE resolution (complexity_metrics.py:363-364, :574-579).
+    1080x1920 and 720x1280 factor into 2, 3, 5 and take the FFT-based row / column passes (k_dct_fft.hip); 1078x1918
+    (= 2 7^2 11 x 2 7 137) does not and takes the fp32 MFMA products (k_dct_full.hip: 128x128 tiles with a ragged edge, the
+    prefetch tail and the |.| reduction).  Checker: scipy.fft.dctn(norm="ortho") in float64 (the C oracle's O(N^3) loop
+    is too slow at this size)."""
     import scipy.fft
     from rtvqa_amd import _native as N
-    h, w = 1080, 1920
     fr = _frames("natural", 3, h, w, seed=23)
     rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_DCT | N.M_TEMPORAL_DCT, dct_mode=N.DCT_FULL)
     coef = [scipy.fft.dctn(co.bgr2gray(f).astype(np.float64), norm="ortho") for f in fr]
@@ -158,9 +160,13 @@ def test_dct_full_frame_1080p_native_vs_scipy(engine):
 
 
 @pytest.mark.parametrize("h,w,rw,rh", [(270, 480, 64, 64), (64, 64, 64, 64), (90, 120, 40, 24),
-                                       (270, 480, 480, 270), (300, 500, 200, 150), (540, 960, 960, 540)])
+                                       (270, 480, 480, 270), (300, 500, 200, 150), (540, 960, 960, 540),
+                                       (300, 500, 262, 134), (300, 500, 256, 134), (300, 500, 134, 256), (300, 500, 128, 128),
+                                       (300, 500, 486, 250), (540, 960, 946, 532)])
 def test_dct_full_frame_parity_mode(engine, h, w, rw, rh):
-    """config.json's own case: full-frame cv2.dct semantics on the resized plane (:363, :574-579)."""
+    """config.json's own case: full-frame cv2.dct semantics on the resized plane (:363, :574-579).  Planes below 128 on a
+    side: vector-ALU products; 480x270, 200x150, 960x540, 128x128, 486x250 (sides even and 2-3-5-smooth): FFT passes
+    (radices 4, 2, 3, 5 all occur); 262x134, 256x134, 134x256, 946x532 (a side with another prime factor): MFMA products."""
     from rtvqa_amd import _native as N
     fr = _frames("natural", 3, h, w, seed=11)
     rec = engine.complexity(fr[1:], prev0=fr[0], mask=N.M_DCT | N.M_TEMPORAL_DCT, resize=(rw, rh),
