@@ -361,7 +361,7 @@ def main():
                          "second context of the device (default for c3ref)")
     ap.add_argument("--inflight", type=int, default=None, choices=[1, 2, 3, 4],
                     help="batches in flight: step i+1 is submitted before step i is waited for, each on its own set of "
-                         "contexts (default 2; c3ref: 1 - its Farneback / full-frame DCT scratch is GiB-sized per context)")
+                         "contexts (default 2; 1 with Farneback motion - GiB-sized scratch per context)")
     ap.add_argument("--pixfmt", default=None, choices=["bgr24", "yuv420p"],
                     help="planes PSNR/SSIM compare: bgr24 (default: B,G,R of the packed frames) or yuv420p (Y + "
                          "quarter-size U,V derived from the same frames: what FFmpeg compares for an H.264 clip)")
@@ -397,9 +397,9 @@ def main():
         if getattr(args, k) is None:
             setattr(args, k, v)
     if args.inflight is None:
-        # Farneback and the full-frame DCT keep GiB-sized scratch per context and saturate the chip on their own: a second
-        # batch in flight thrashes (measured: c3 + Farneback 2946 fps with one batch in flight, 1684 with two)
-        args.inflight = 1 if (args.motion == "farneback" or args.dct_mode == "full") else 2
+        # Farneback keeps GiB-sized scratch per context and saturates the chip on its own: a second batch in flight
+        # thrashes (measured: c3 + Farneback 2946 fps with one batch in flight, 1684 with two)
+        args.inflight = 1 if args.motion == "farneback" else 2
     h, w, full = wl["h"], wl["w"], wl["full"]
     B = args.batch or wl["batch"]
     stub = args.stub_engine
