@@ -3,7 +3,7 @@
 set -e
 R=${1:-round4}
 cd "$(dirname "$0")/.."
-for t in c2 c3 c2ff c4 c3fb c3noise c3ref; do
+for t in c2 c3 c2ff c4 c3fb c3noise c3ref c3full; do
   f=$(ls -t gpurun_out/prof_final_$t/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" profiles/${R}_${t}_kernel_stats.csv
   [ -f gpurun_out/bench_final_$t.log ] && tail -1 gpurun_out/bench_final_$t.log > profiles/${R}_${t}_bench.json
