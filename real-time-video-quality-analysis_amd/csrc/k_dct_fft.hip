@@ -7,15 +7,15 @@
 // "full-frame DCT via mixed-radix (1080 = 2^3 3^3 5, 1920 = 2^7 3 5) row/column passes".
 // k_dct_full.hip computes Y = C_h X C_w^T as two dense products (12.4 GFLOP per 1080p frame pair, on the matrix
 // cores); this file computes the same orthonormal 2-D DCT-II in O(P log P): every 1-D DCT is ONE complex FFT of the
-// same length (Makhoul's reordering v[n] = x[2n], v[N-1-n] = x[2n+1]; C[k] = Re(e^{-i pi k / 2N} V[k])), and the two
-// real sequences the metrics need - the current plane for the energy, prev - curr for the temporal L1 (linearity:
-// dct(prev) - dct(curr) = dct(prev - curr)) - ride in the real and imaginary parts of that one FFT
-// (A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i).
+// same length (Makhoul's reordering v[n] = x[2n], v[N-1-n] = x[2n+1]; C[k] = Re(e^{-i pi k / 2N} V[k])), and TWO real
+// sequences - two adjacent rows, then two adjacent columns, of the same plane - ride in the real and imaginary parts of
+// one FFT (A[k] = (Z[k] + conj Z[N-k]) / 2, B[k] = (Z[k] - conj Z[N-k]) / 2i).  Two planes are transformed: the current
+// plane for the energy, prev - curr for the temporal L1 (linearity: dct(prev) - dct(curr) = dct(prev - curr)).
 //
 //   k_dct_fft_rows: one workgroup transforms rows: u8 samples -> LDS (centred at 128: the constant's DC term is put
 //                   back analytically, which keeps the FFT's rounding noise relative to the texture, not to the
 //                   offset) -> Stockham autosort passes of radix 8 / 4 / 2 / 3 / 5 in LDS -> two float planes.
-//   k_dct_fft_cols: one workgroup transforms a tile of adjacent columns of both planes the same way and reduces
+//   k_dct_fft_cols: one workgroup transforms a pair of adjacent columns of both planes the same way and reduces
 //                   sum Ya^2 and sum |Yb| on the fly: the 2-D coefficients are never written.
 // Lengths must be even and factor into 2, 3, 5 (1080p, 2160p, 720p, 480p ... do); other sizes take k_dct_full.hip.
 // No dense contraction is left, so nothing here uses MFMA.  Roofline: HBM (P bytes in + 8P out, 8P in per frame);
@@ -138,11 +138,12 @@ __device__ __forceinline__ float2 dct_from_fft(const float2 *Z, int k, int N, fl
     return make_float2(post.x * ax + post.y * ay, post.x * bx + post.y * by);
 }
 
-// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = (2 + TWL) * w * 8 bytes
+// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = (2 + TWL) * w * 8 bytes; rows_per_wg is even.
+// One FFT transforms a PAIR of rows of the SAME plane (row r in the real part, row r + 1 in the imaginary part).
 template <bool TWL>
 __global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride, int h,
                                                       int w, dct_fft_plan P, float *__restrict__ Ra, float *__restrict__ Rb,
-                                                      int rows_per_wg)
+                                                      int rows_per_wg, int want_a, int want_b)
 {
     extern __shared__ float2 lds_fft[];
     float2 *b0 = lds_fft, *b1 = lds_fft + w;
@@ -156,58 +157,76 @@ __global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict_
     const uint8_t *cur = planes + (int64_t)(f + 1) * plane_stride, *prev = planes + (int64_t)f * plane_stride;
     const float dc = 128.f * sqrtf((float)w); // row-DCT of the constant that was subtracted
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
-    for (int r = r0; r < r1; r++) {
-        __syncthreads(); // the previous row's readers are done (and the twiddle table is complete)
-        for (int n = tid; n < w; n += 256) {
-            const int cv = cur[(int64_t)r * pitch + n], pv = prev[(int64_t)r * pitch + n];
-            b0[makhoul_pos(n, w)] = make_float2((float)(cv - 128), (float)(pv - cv));
-        }
-        __syncthreads();
-        const float2 *Z = fft_run(P, b0, b1, tw, 1, tid, 256);
-        float *oa = Ra + ((int64_t)f * h + r) * w, *ob = Rb + ((int64_t)f * h + r) * w;
-        for (int k = tid; k < w; k += 256) {
-            const float2 c = dct_from_fft(Z, k, w, P.post[k]);
-            oa[k] = k ? c.x : c.x + dc;
-            ob[k] = c.y;
+    for (int r = r0; r < r1; r += 2) {          // h is even
+        for (int pl = 0; pl < 2; pl++) {        // 0: the plane itself (centred), 1: prev - curr
+            if (!(pl ? want_b : want_a)) continue; // (wave-uniform)
+            __syncthreads(); // the previous transform's readers are done (and the twiddle table is complete)
+            for (int n = tid; n < w; n += 256) {
+                const int c0 = cur[(int64_t)r * pitch + n], c1 = cur[(int64_t)(r + 1) * pitch + n];
+                float2 v;
+                if (pl == 0) v = make_float2((float)(c0 - 128), (float)(c1 - 128));
+                else v = make_float2((float)((int)prev[(int64_t)r * pitch + n] - c0), (float)((int)prev[(int64_t)(r + 1) * pitch + n] - c1));
+                b0[makhoul_pos(n, w)] = v;
+            }
+            __syncthreads();
+            const float2 *Z = fft_run(P, b0, b1, tw, 1, tid, 256);
+            float *o0 = (pl ? Rb : Ra) + ((int64_t)f * h + r) * w, *o1 = o0 + w;
+            const float add = pl ? 0.f : dc;
+            for (int k = tid; k < w; k += 256) {
+                const float2 c = dct_from_fft(Z, k, w, P.post[k]);
+                o0[k] = k ? c.x : c.x + add;
+                o1[k] = k ? c.y : c.y + add;
+            }
         }
     }
 }
 
-// grid = (ceil(w / ct), n_frames), block = 256, dynamic LDS = (2 ct + TWL) * h * 8 bytes
-template <bool TWL>
+// grid = (8 * ceil(w / 2 / 8), n_frames), block = 256.  A workgroup takes the column pair (x0, x0 + 1) of both planes:
+// two FFTs (one per plane; column x0 in the real part, x0 + 1 in the imaginary part), CONCURRENT when the LDS holds both
+// (dynamic LDS = (4 + 1) * h * 8 bytes), else one after the other ((2 + 1) * h * 8).  sum Ya^2 and sum |Yb| are reduced
+// on the fly: the 2-D coefficients are never written.
+template <bool BOTH>
 __global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ Ra, const float *__restrict__ Rb, int h, int w,
-                                                      dct_fft_plan P, int ct, double *__restrict__ pe, double *__restrict__ pt)
+                                                      dct_fft_plan P, double *__restrict__ pe, double *__restrict__ pt, int want_a,
+                                                      int want_b)
 {
     extern __shared__ float2 lds_fft[];
     __shared__ double red[4];
-    float2 *b0 = lds_fft, *b1 = lds_fft + ct * h;
-    const float2 *tw = P.tw;
+    constexpr int NSEQ = BOTH ? 2 : 1;
+    float2 *b0 = lds_fft, *b1 = lds_fft + NSEQ * h, *twl = lds_fft + 2 * NSEQ * h;
     const int tid = threadIdx.x, f = blockIdx.y;
-    if (TWL) {
-        float2 *twl = lds_fft + 2 * ct * h;
-        for (int i = tid; i < h; i += 256) twl[i] = P.tw[i];
-        tw = twl;
-    }
-    // XCD-aware tile order (workgroup ids go round-robin over the 8 XCDs): XCD c takes a contiguous range of column tiles,
+    for (int i = tid; i < h; i += 256) twl[i] = P.tw[i];
+    // XCD-aware tile order (workgroup ids go round-robin over the 8 XCDs): XCD c takes a contiguous range of column pairs,
     // so the neighbours that share 64-byte sectors of a row meet in ONE L2
     const int per = ((int)gridDim.x + 7) >> 3;
     const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
-    const int ntiles = (w + ct - 1) / ct;
+    const int ntiles = w >> 1;
     if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles) return;
-    const int x0 = tile * ct, nc = min(ct, w - x0);
+    const int x0 = tile * 2;
     const float *pa = Ra + (int64_t)f * h * w + x0, *pb = Rb + (int64_t)f * h * w + x0;
-    for (int i = tid; i < nc * h; i += 256) {
-        const int m = i / nc, c = i - m * nc;
-        b0[c * h + makhoul_pos(m, h)] = make_float2(pa[(int64_t)m * w + c], pb[(int64_t)m * w + c]);
-    }
-    __syncthreads();
-    const float2 *Z = fft_run(P, b0, b1, tw, nc, tid, 256);
     double e = 0, t = 0;
-    for (int i = tid; i < nc * h; i += 256) {
-        const int c = i / h, k = i - c * h;
-        const float2 y = dct_from_fft(Z + c * h, k, h, P.post[k]);
-        e += (double)y.x * (double)y.x;
-        t += (double)fabsf(y.y);
+    auto load = [&](const float *src, float2 *dst) {
+        for (int m = tid; m < h; m += 256) dst[makhoul_pos(m, h)] = *(const float2 *)(src + (int64_t)m * w); // x0 is even: 8-byte aligned
+    };
+    auto reduce = [&](const float2 *Z, bool energy) {
+        for (int k = tid; k < h; k += 256) {
+            const float2 y = dct_from_fft(Z, k, h, P.post[k]);
+            if (energy) e += (double)y.x * (double)y.x + (double)y.y * (double)y.y;
+            else t += (double)fabsf(y.x) + (double)fabsf(y.y);
+        }
+    };
+    // ONE call site of the transform for every mask (energy only, temporal only, both): the same inlined arithmetic, so a
+    // metric's bits do not depend on which other metric was asked for
+    int which[2], np_ = 0;
+    if (want_a) which[np_++] = 0;
+    if (want_b) which[np_++] = 1;
+    for (int p0 = 0; p0 < np_; p0 += NSEQ) {
+        const int ns = min(NSEQ, np_ - p0);
+        __syncthreads(); // the previous round's readers are done
+        for (int q = 0; q < ns; q++) load(which[p0 + q] ? pb : pa, b0 + q * h);
+        __syncthreads();
+        const float2 *Z = fft_run(P, b0, b1, twl, ns, tid, 256);
+        for (int q = 0; q < ns; q++) reduce(Z + q * h, which[p0 + q] == 0);
     }
     const double es = block_sum(e, red);
     const double ts = block_sum(t, red);
@@ -233,28 +252,19 @@ bool dct_fft_factor(int n, int radix[DCT_FFT_MAX_PASSES], int *npass)
     return true;
 }
 
-// columns per workgroup of the column pass: as many as 64 KiB of LDS hold (two buffers per column + the twiddle table):
-// 3 at 1080 rows.  Measured at 1080p, 64 frames: 3 columns (60 KB, two workgroups per CU) 1.96 ms; 8 columns with the
-// 144 KB a gfx950 workgroup may ask for (32-byte row segments, ONE workgroup per CU) 2.49 ms - the pass is bound by
-// the barriers between its short radix passes, i.e. by occupancy, not by how well its loads coalesce.
-static int dct_fft_ct(int h)
-{
-    int ct = (64 * 1024 - 64 - h * 8) / (2 * h * 8);
-    return ct < 1 ? 1 : (ct > 8 ? 8 : ct);
-}
-
-// both sides factor, and a column (two buffers + the twiddle table) fits the 64 KiB every runtime grants
+// Packing history: the first version put the plane in the real part and prev - curr in the imaginary part of ONE
+// FFT.  The separation (Z[k] +- conj Z[N-k]) / 2 is exact only in exact arithmetic: rounding noise of the LARGE plane
+// leaks into the SMALL difference (~1e-7 of sum |A|: identical frames read 0.5 instead of 0, a static scene with a few
+// changed pixels is off by per cents).  Packing two rows / columns of the SAME plane keeps the leak relative to that
+// plane's own magnitude, and a zero difference stays exactly zero.
+// both sides factor, and one column transform (two buffers + the twiddle table) fits 64 KiB of LDS
 bool dct_fft_supported(int h, int w)
 {
     int rx[DCT_FFT_MAX_PASSES], np;
     return h <= 2560 && dct_fft_factor(h, rx, &np) && dct_fft_factor(w, rx, &np);
 }
 
-int dct_fft_tiles(int h, int w)
-{
-    const int ct = dct_fft_ct(h);
-    return (w + ct - 1) / ct;
-}
+int dct_fft_tiles(int h, int w) { (void)h; return w >> 1; } // one partial pair per column pair
 
 // planes: slot 0 = frame before the batch, slot i+1 = batch frame i (u8, pitch).  scratch: 2 * n * h * w floats.
 // pe / pt: n * dct_fft_tiles(h, w) doubles each.  The finalize kernel is k_dct_full.hip's.
@@ -268,13 +278,17 @@ void launch_dct_full_fft(hipStream_t st, const uint8_t *planes, int pitch, int64
     const int rpw = 8;
     const dim3 gr((h + rpw - 1) / rpw, n);
     if (twl_w)
-        hipLaunchKernelGGL(k_dct_fft_rows<true>, gr, dim3(256), (size_t)3 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb, rpw);
+        hipLaunchKernelGGL(k_dct_fft_rows<true>, gr, dim3(256), (size_t)3 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb,
+                           rpw, (int)energy, (int)temporal);
     else
-        hipLaunchKernelGGL(k_dct_fft_rows<false>, gr, dim3(256), (size_t)2 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb, rpw);
-    const int ct = dct_fft_ct(h);
-    const int tiles = (w + ct - 1) / ct;
+        hipLaunchKernelGGL(k_dct_fft_rows<false>, gr, dim3(256), (size_t)2 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb,
+                           rpw, (int)energy, (int)temporal);
+    const int tiles = w >> 1;
     const dim3 gc((tiles + 7) / 8 * 8, n);
-    hipLaunchKernelGGL(k_dct_fft_cols<true>, gc, dim3(256), (size_t)(2 * ct + 1) * h * 8, st, Ra, Rb, h, w, ph_, ct, pe, pt);
+    if (5 * h * 8 <= 64 * 1024 - 64)
+        hipLaunchKernelGGL(k_dct_fft_cols<true>, gc, dim3(256), (size_t)5 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
+    else
+        hipLaunchKernelGGL(k_dct_fft_cols<false>, gc, dim3(256), (size_t)3 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
     launch_dct_full_finalize(st, pe, pt, tiles, n, res, energy, temporal, first_has_prev);
 }
 

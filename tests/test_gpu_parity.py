@@ -159,6 +159,30 @@ def test_dct_full_frame_1080p_native_vs_scipy(engine, h, w):
     assert _rel(rec[0]["temporal_dct_l1"], 3 * np.sqrt(h * w)) < RTOL
 
 
+@pytest.mark.parametrize("h,w", [(270, 480), (1080, 1920), (134, 262)])
+def test_dct_full_frame_static_and_nearly_static_scenes(engine, h, w):
+    """The temporal full-frame metric on a scene that does not move: identical frames must give EXACTLY 0 (the reference
+    subtracts two identical coefficient arrays), and a frame that differs from its predecessor in a handful of pixels
+    must keep the 1e-4 bar although its L1 is six orders of magnitude below the plane's own coefficients.  The first
+    FFT version packed the plane and the difference into one complex transform and read 0.5 instead of 0 here: rounding
+    noise of the large plane leaks into the small difference.  (134 x 262 takes the dense products.)"""
+    import scipy.fft
+    from rtvqa_amd import _native as N
+    fr = _frames("natural", 1, h, w, seed=57)
+    same = np.repeat(fr, 3, axis=0)
+    rec = engine.complexity(same[1:], prev0=same[0], mask=N.M_DCT | N.M_TEMPORAL_DCT, dct_mode=N.DCT_FULL)
+    assert float(rec[0]["temporal_dct_l1"]) == 0.0 and float(rec[1]["temporal_dct_l1"]) == 0.0
+    assert _rel(rec[0]["dct_energy"], float(rec[0]["sum_gray2"])) < 1e-5
+    near = same.copy()
+    near[1, h // 3, w // 2] ^= 0x40           # one pixel, all three channels
+    near[2, h // 2:h // 2 + 2, 5:9] //= 2     # a 2 x 4 patch
+    rec = engine.complexity(near[1:], prev0=near[0], mask=N.M_TEMPORAL_DCT, dct_mode=N.DCT_FULL)
+    g = [co.bgr2gray(f).astype(np.float64) for f in near]
+    for i in range(2):
+        want = float(np.abs(scipy.fft.dctn(g[i], norm="ortho") - scipy.fft.dctn(g[i + 1], norm="ortho")).sum())
+        assert want > 0 and _rel(rec[i]["temporal_dct_l1"], want) < RTOL, (i, float(rec[i]["temporal_dct_l1"]), want)
+
+
 @pytest.mark.parametrize("h,w,rw,rh", [(270, 480, 64, 64), (64, 64, 64, 64), (90, 120, 40, 24),
                                        (270, 480, 480, 270), (300, 500, 200, 150), (540, 960, 960, 540),
                                        (300, 500, 262, 134), (300, 500, 256, 134), (300, 500, 134, 256), (300, 500, 128, 128),
