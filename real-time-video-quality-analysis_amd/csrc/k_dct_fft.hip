@@ -138,44 +138,55 @@ __device__ __forceinline__ float2 dct_from_fft(const float2 *Z, int k, int N, fl
     return make_float2(post.x * ax + post.y * ay, post.x * bx + post.y * by);
 }
 
-// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = (2 + TWL) * w * 8 bytes; rows_per_wg is even.
-// One FFT transforms a PAIR of rows of the SAME plane (row r in the real part, row r + 1 in the imaginary part).
-template <bool TWL>
+// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = (2 NSEQ + TWL) * w * 8 bytes; rows_per_wg is even.
+// One FFT transforms a PAIR of rows of the SAME plane (row r in the real part, row r + 1 in the imaginary part); with
+// NSEQ = 2 the pair of the plane and the pair of prev - curr go through the passes together (half the barriers per row).
+template <int NSEQ, bool TWL>
 __global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride, int h,
                                                       int w, dct_fft_plan P, float *__restrict__ Ra, float *__restrict__ Rb,
                                                       int rows_per_wg, int want_a, int want_b)
 {
     extern __shared__ float2 lds_fft[];
-    float2 *b0 = lds_fft, *b1 = lds_fft + w;
+    float2 *b0 = lds_fft, *b1 = lds_fft + NSEQ * w;
     const float2 *tw = P.tw;
     const int tid = threadIdx.x, f = blockIdx.y;
     if (TWL) {
-        float2 *twl = lds_fft + 2 * w;
+        float2 *twl = lds_fft + 2 * NSEQ * w;
         for (int i = tid; i < w; i += 256) twl[i] = P.tw[i];
         tw = twl;
     }
     const uint8_t *cur = planes + (int64_t)(f + 1) * plane_stride, *prev = planes + (int64_t)f * plane_stride;
     const float dc = 128.f * sqrtf((float)w); // row-DCT of the constant that was subtracted
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
+    int which[2], np_ = 0; // 0: the plane itself (centred), 1: prev - curr
+    if (want_a) which[np_++] = 0;
+    if (want_b) which[np_++] = 1;
     for (int r = r0; r < r1; r += 2) {          // h is even
-        for (int pl = 0; pl < 2; pl++) {        // 0: the plane itself (centred), 1: prev - curr
-            if (!(pl ? want_b : want_a)) continue; // (wave-uniform)
+        for (int p0 = 0; p0 < np_; p0 += NSEQ) {
+            const int ns = min(NSEQ, np_ - p0);
             __syncthreads(); // the previous transform's readers are done (and the twiddle table is complete)
-            for (int n = tid; n < w; n += 256) {
-                const int c0 = cur[(int64_t)r * pitch + n], c1 = cur[(int64_t)(r + 1) * pitch + n];
-                float2 v;
-                if (pl == 0) v = make_float2((float)(c0 - 128), (float)(c1 - 128));
-                else v = make_float2((float)((int)prev[(int64_t)r * pitch + n] - c0), (float)((int)prev[(int64_t)(r + 1) * pitch + n] - c1));
-                b0[makhoul_pos(n, w)] = v;
+            for (int q = 0; q < ns; q++) {
+                const int pl = which[p0 + q];
+                float2 *dst = b0 + q * w;
+                for (int n = tid; n < w; n += 256) {
+                    const int c0 = cur[(int64_t)r * pitch + n], c1 = cur[(int64_t)(r + 1) * pitch + n];
+                    float2 v;
+                    if (pl == 0) v = make_float2((float)(c0 - 128), (float)(c1 - 128));
+                    else v = make_float2((float)((int)prev[(int64_t)r * pitch + n] - c0), (float)((int)prev[(int64_t)(r + 1) * pitch + n] - c1));
+                    dst[makhoul_pos(n, w)] = v;
+                }
             }
             __syncthreads();
-            const float2 *Z = fft_run(P, b0, b1, tw, 1, tid, 256);
-            float *o0 = (pl ? Rb : Ra) + ((int64_t)f * h + r) * w, *o1 = o0 + w;
-            const float add = pl ? 0.f : dc;
-            for (int k = tid; k < w; k += 256) {
-                const float2 c = dct_from_fft(Z, k, w, P.post[k]);
-                o0[k] = k ? c.x : c.x + add;
-                o1[k] = k ? c.y : c.y + add;
+            const float2 *Z = fft_run(P, b0, b1, tw, ns, tid, 256); // ONE call site for every mask
+            for (int q = 0; q < ns; q++) {
+                const int pl = which[p0 + q];
+                float *o0 = (pl ? Rb : Ra) + ((int64_t)f * h + r) * w, *o1 = o0 + w;
+                const float add = pl ? 0.f : dc;
+                for (int k = tid; k < w; k += 256) {
+                    const float2 c = dct_from_fft(Z + q * w, k, w, P.post[k]);
+                    o0[k] = k ? c.x : c.x + add;
+                    o1[k] = k ? c.y : c.y + add;
+                }
             }
         }
     }
@@ -274,15 +285,16 @@ void launch_dct_full_fft(hipStream_t st, const uint8_t *planes, int pitch, int64
 {
     if (n <= 0 || (!energy && !temporal)) return;
     float *Ra = scratch, *Rb = scratch + (int64_t)n * h * w;
-    const bool twl_w = 3 * w * 8 <= 64 * 1024 - 64;
-    const int rpw = 8;
+    const int cap = 64 * 1024 - 64, rpw = 8;
     const dim3 gr((h + rpw - 1) / rpw, n);
-    if (twl_w)
-        hipLaunchKernelGGL(k_dct_fft_rows<true>, gr, dim3(256), (size_t)3 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb,
-                           rpw, (int)energy, (int)temporal);
-    else
-        hipLaunchKernelGGL(k_dct_fft_rows<false>, gr, dim3(256), (size_t)2 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb,
-                           rpw, (int)energy, (int)temporal);
+#define ROWS(NS, TW)                                                                                                         \
+    hipLaunchKernelGGL((k_dct_fft_rows<NS, TW>), gr, dim3(256), (size_t)(2 * NS + (TW ? 1 : 0)) * w * 8, st, planes, pitch,     \
+                       plane_stride, h, w, pw_, Ra, Rb, rpw, (int)energy, (int)temporal)
+    // (NSEQ = 2 - both planes' row pairs through the passes together - measured SLOWER at every size: 1080p 1.52 ms against
+    // 1.11, 720p 0.45 against 0.37, 540p 0.22 against 0.20: larger LDS footprint, fewer workgroups per CU)
+    if (3 * w * 8 <= cap) ROWS(1, true);   // twiddles in LDS        (w <= 2728)
+    else ROWS(1, false);                   // twiddles through L1     (w <= 4096: 2160p)
+#undef ROWS
     const int tiles = w >> 1;
     const dim3 gc((tiles + 7) / 8 * 8, n);
     if (5 * h * 8 <= 64 * 1024 - 64)
