@@ -86,14 +86,15 @@ __device__ __forceinline__ void dft<5>(float2 *v)
 // One Stockham autosort pass of radix R over `cols` independent sequences of length N stored back to back:
 // butterfly j of a sequence reads in[j + t N/R], twiddles input t by e^{-2 pi i t k / (Ns R)} (k = j mod Ns, Ns = the
 // product of the radices already applied) and writes out[(j - k) R + k + t Ns].  tw[m] = e^{-2 pi i m / N}.
+// (No integer division in the loop: the GPU has none in hardware and two of them doubled the instruction count of a
+// butterfly.  M and tstep come with the plan; j mod Ns is a multiply-high by ceil(2^32 / Ns), exact while j Ns < 2^32.)
 template <int R>
 __device__ __forceinline__ void fft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
-                                         int N, int Ns, int cols, int tid, int nthreads)
+                                         int N, int Ns, uint32_t ns_magic, int M, int tstep, int cols, int tid, int nthreads)
 {
-    const int M = N / R, tstep = N / (Ns * R);
-    for (int i = tid; i < cols * M; i += nthreads) {
-        const int c = i / M, j = i - c * M;
-        const int k = j % Ns;
+    for (int c = 0; c < cols; c++)
+    for (int j = tid; j < M; j += nthreads) {
+        const int k = Ns == 1 ? 0 : j - (int)__umulhi((uint32_t)j, ns_magic) * Ns; // j mod Ns  (Ns == 1: wave-uniform)
         const float2 *src = in + c * N + j;
         float2 v[R];
         v[0] = src[0];
@@ -114,11 +115,13 @@ __device__ __forceinline__ float2 *fft_run(const dct_fft_plan &P, float2 *b0, fl
     int Ns = 1;
     for (int p = 0; p < P.npass; p++) {
         const int R = P.radix[p];
-        if (R == 8) fft_pass<8>(in, out, tw, P.n, Ns, cols, tid, nthreads);
-        else if (R == 4) fft_pass<4>(in, out, tw, P.n, Ns, cols, tid, nthreads);
-        else if (R == 2) fft_pass<2>(in, out, tw, P.n, Ns, cols, tid, nthreads);
-        else if (R == 3) fft_pass<3>(in, out, tw, P.n, Ns, cols, tid, nthreads);
-        else fft_pass<5>(in, out, tw, P.n, Ns, cols, tid, nthreads);
+        const uint32_t mg = P.ns_magic[p];
+        const int M = P.m[p], ts = P.tstep[p];
+        if (R == 8) fft_pass<8>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        else if (R == 4) fft_pass<4>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        else if (R == 2) fft_pass<2>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        else if (R == 3) fft_pass<3>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        else fft_pass<5>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
         __syncthreads();
         float2 *t = in; in = out; out = t;
         Ns *= R;

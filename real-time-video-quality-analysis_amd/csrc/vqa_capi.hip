@@ -250,6 +250,12 @@ static int get_fft_plan(vqa_ctx *c, int n, dct_fft_plan *out)
     memset(&P, 0, sizeof P);
     P.n = n;
     if (!dct_fft_factor(n, P.radix, &P.npass)) return VQA_ERR_UNSUPPORTED;
+    for (int p = 0, Ns = 1; p < P.npass; Ns *= P.radix[p], p++) {
+        P.m[p] = n / P.radix[p];
+        P.tstep[p] = n / (Ns * P.radix[p]);
+        // j / Ns = mulhi(j, ceil(2^32 / Ns)), exact while j * Ns < 2^32 (n <= 4096); the first pass (Ns = 1) does not use it
+        P.ns_magic[p] = Ns == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)Ns - 1) / (uint64_t)Ns);
+    }
     std::vector<float2> tw((size_t)n), post((size_t)n);
     for (int m = 0; m < n; m++) {
         const double a = -2.0 * M_PI * (double)m / (double)n;

@@ -61,6 +61,8 @@ constexpr int DCT_FFT_MAX_PASSES = 12;
 struct dct_fft_plan {            // one per transform length
     int n, npass;
     int radix[DCT_FFT_MAX_PASSES];
+    int m[DCT_FFT_MAX_PASSES], tstep[DCT_FFT_MAX_PASSES];   // per pass: n / radix, n / (Ns radix)   (Ns = product of the radices before it)
+    uint32_t ns_magic[DCT_FFT_MAX_PASSES];                 // per pass: ceil(2^32 / Ns): j / Ns = mulhi(j, magic) for j Ns < 2^32 (Ns = 1: 0, see k_dct_fft.hip)
     const float2 *tw;            // device: tw[m] = e^{-2 pi i m / n}, m < n
     const float2 *post;          // device: post[k] = s_k (cos, sin)(pi k / 2n), s_0 = sqrt(1/n), s_k = sqrt(2/n)
 };
