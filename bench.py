@@ -679,14 +679,14 @@ def main():
                 "farneback(pyramid)": 440 * P * B,
             }
             def _smooth(n):  # the library's rule (k_dct_fft.hip, dct_fft_factor): even, 128..4096, prime factors 2, 3, 5
-                if n < 128 or n > 4096 or n % 2:
+                if n < 128 or n > 4000 or n % 2:
                     return False
                 for q in (2, 3, 5):
                     while n % q == 0:
                         n //= q
                 return n == 1
             mfma_flops = {}
-            if _smooth(h) and _smooth(w) and h <= 2560:
+            if _smooth(h) and _smooth(w):
                 # FFT-based row / column passes: both u8 planes read (2P), two float planes written (8P) and read back (8P)
                 alg_bytes["k_dct_full"] = 18 * P * B
             else:

@@ -141,23 +141,20 @@ __device__ __forceinline__ float2 dct_from_fft(const float2 *Z, int k, int N, fl
     return make_float2(post.x * ax + post.y * ay, post.x * bx + post.y * by);
 }
 
-// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = (2 NSEQ + TWL) * w * 8 bytes; rows_per_wg is even.
+// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = 2 NSEQ * w * 8 bytes; rows_per_wg is even.
 // One FFT transforms a PAIR of rows of the SAME plane (row r in the real part, row r + 1 in the imaginary part); with
 // NSEQ = 2 the pair of the plane and the pair of prev - curr go through the passes together (half the barriers per row).
-template <int NSEQ, bool TWL>
+template <int NSEQ>
 __global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride, int h,
                                                       int w, dct_fft_plan P, float *__restrict__ Ra, float *__restrict__ Rb,
                                                       int rows_per_wg, int want_a, int want_b)
 {
     extern __shared__ float2 lds_fft[];
     float2 *b0 = lds_fft, *b1 = lds_fft + NSEQ * w;
+    // twiddles come from the plan's table in global memory (L1-resident): a copy in LDS cost 15 KB per workgroup, i.e. two of
+    // the five workgroups a CU can hold, and these passes live on occupancy (1.00 ms with the copy, 0.90 without, 1080p)
     const float2 *tw = P.tw;
     const int tid = threadIdx.x, f = blockIdx.y;
-    if (TWL) {
-        float2 *twl = lds_fft + 2 * NSEQ * w;
-        for (int i = tid; i < w; i += 256) twl[i] = P.tw[i];
-        tw = twl;
-    }
     const uint8_t *cur = planes + (int64_t)(f + 1) * plane_stride, *prev = planes + (int64_t)f * plane_stride;
     const float dc = 128.f * sqrtf((float)w); // row-DCT of the constant that was subtracted
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
@@ -167,7 +164,7 @@ __global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict_
     for (int r = r0; r < r1; r += 2) {          // h is even
         for (int p0 = 0; p0 < np_; p0 += NSEQ) {
             const int ns = min(NSEQ, np_ - p0);
-            __syncthreads(); // the previous transform's readers are done (and the twiddle table is complete)
+            __syncthreads(); // the previous transform's readers are done
             for (int q = 0; q < ns; q++) {
                 const int pl = which[p0 + q];
                 float2 *dst = b0 + q * w;
@@ -197,7 +194,7 @@ __global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict_
 
 // grid = (8 * ceil(w / 2 / 8), n_frames), block = 256.  A workgroup takes the column pair (x0, x0 + 1) of both planes:
 // two FFTs (one per plane; column x0 in the real part, x0 + 1 in the imaginary part), CONCURRENT when the LDS holds both
-// (dynamic LDS = (4 + 1) * h * 8 bytes), else one after the other ((2 + 1) * h * 8).  sum Ya^2 and sum |Yb| are reduced
+// (dynamic LDS = 4 * h * 8 bytes), else one after the other (2 * h * 8).  sum Ya^2 and sum |Yb| are reduced
 // on the fly: the 2-D coefficients are never written.
 template <bool BOTH>
 __global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ Ra, const float *__restrict__ Rb, int h, int w,
@@ -207,9 +204,9 @@ __global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ 
     extern __shared__ float2 lds_fft[];
     __shared__ double red[4];
     constexpr int NSEQ = BOTH ? 2 : 1;
-    float2 *b0 = lds_fft, *b1 = lds_fft + NSEQ * h, *twl = lds_fft + 2 * NSEQ * h;
+    float2 *b0 = lds_fft, *b1 = lds_fft + NSEQ * h;
+    const float2 *twl = P.tw; // (global / L1, as in the row pass)
     const int tid = threadIdx.x, f = blockIdx.y;
-    for (int i = tid; i < h; i += 256) twl[i] = P.tw[i];
     // XCD-aware tile order (workgroup ids go round-robin over the 8 XCDs): XCD c takes a contiguous range of column pairs,
     // so the neighbours that share 64-byte sectors of a row meet in ONE L2
     const int per = ((int)gridDim.x + 7) >> 3;
@@ -254,7 +251,7 @@ __global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ 
 // radix-8 passes first, then 4, 2, 3, 5; false if n is odd, has another prime factor, or is too short / too long to pay
 bool dct_fft_factor(int n, int radix[DCT_FFT_MAX_PASSES], int *npass)
 {
-    if (n < 128 || n > 4096 || (n & 1)) return false;
+    if (n < 128 || n > 4000 || (n & 1)) return false; // (two buffers of n float2 within 64 KiB of LDS)
     int m = n, np = 0;
     while (m % 8 == 0 && np < DCT_FFT_MAX_PASSES) { radix[np++] = 8; m /= 8; }
     while (m % 4 == 0 && np < DCT_FFT_MAX_PASSES) { radix[np++] = 4; m /= 4; }
@@ -271,11 +268,11 @@ bool dct_fft_factor(int n, int radix[DCT_FFT_MAX_PASSES], int *npass)
 // leaks into the SMALL difference (~1e-7 of sum |A|: identical frames read 0.5 instead of 0, a static scene with a few
 // changed pixels is off by per cents).  Packing two rows / columns of the SAME plane keeps the leak relative to that
 // plane's own magnitude, and a zero difference stays exactly zero.
-// both sides factor, and one column transform (two buffers + the twiddle table) fits 64 KiB of LDS
+// both sides factor (a transform of up to 4096 points - two buffers - fits 64 KiB of LDS)
 bool dct_fft_supported(int h, int w)
 {
     int rx[DCT_FFT_MAX_PASSES], np;
-    return h <= 2560 && dct_fft_factor(h, rx, &np) && dct_fft_factor(w, rx, &np);
+    return dct_fft_factor(h, rx, &np) && dct_fft_factor(w, rx, &np);
 }
 
 int dct_fft_tiles(int h, int w) { (void)h; return w >> 1; } // one partial pair per column pair
@@ -288,22 +285,18 @@ void launch_dct_full_fft(hipStream_t st, const uint8_t *planes, int pitch, int64
 {
     if (n <= 0 || (!energy && !temporal)) return;
     float *Ra = scratch, *Rb = scratch + (int64_t)n * h * w;
-    const int cap = 64 * 1024 - 64, rpw = 8;
+    const int cap = 64 * 1024, rpw = 8;
     const dim3 gr((h + rpw - 1) / rpw, n);
-#define ROWS(NS, TW)                                                                                                         \
-    hipLaunchKernelGGL((k_dct_fft_rows<NS, TW>), gr, dim3(256), (size_t)(2 * NS + (TW ? 1 : 0)) * w * 8, st, planes, pitch,     \
-                       plane_stride, h, w, pw_, Ra, Rb, rpw, (int)energy, (int)temporal)
     // (NSEQ = 2 - both planes' row pairs through the passes together - measured SLOWER at every size: 1080p 1.52 ms against
     // 1.11, 720p 0.45 against 0.37, 540p 0.22 against 0.20: larger LDS footprint, fewer workgroups per CU)
-    if (3 * w * 8 <= cap) ROWS(1, true);   // twiddles in LDS        (w <= 2728)
-    else ROWS(1, false);                   // twiddles through L1     (w <= 4096: 2160p)
-#undef ROWS
+    hipLaunchKernelGGL((k_dct_fft_rows<1>), gr, dim3(256), (size_t)2 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb, rpw,
+                       (int)energy, (int)temporal);
     const int tiles = w >> 1;
     const dim3 gc((tiles + 7) / 8 * 8, n);
-    if (5 * h * 8 <= 64 * 1024 - 64)
-        hipLaunchKernelGGL(k_dct_fft_cols<true>, gc, dim3(256), (size_t)5 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
+    if (4 * h * 8 <= cap - 64)
+        hipLaunchKernelGGL(k_dct_fft_cols<true>, gc, dim3(256), (size_t)4 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
     else
-        hipLaunchKernelGGL(k_dct_fft_cols<false>, gc, dim3(256), (size_t)3 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
+        hipLaunchKernelGGL(k_dct_fft_cols<false>, gc, dim3(256), (size_t)2 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
     launch_dct_full_finalize(st, pe, pt, tiles, n, res, energy, temporal, first_has_prev);
 }
 
