@@ -38,71 +38,146 @@ __device__ __forceinline__ int fb_reflect101(int i, int n)
 // ---- Gaussian blur, horizontal pass straight from the u8 gray plane -------------------------------
 // Only the columns in `cols` (all when null) are produced: at the coarse levels the bilinear resize that
 // follows samples 2 of every 4 or 8 columns and rows, and nothing else reads the blurred plane.
-// grid = (ceil(nc/256), h, planes)
+// A workgroup takes FB_RB rows of its 256 columns: with one row each, a 1080p batch was ~280 000 workgroups of one
+// output per thread and every one of these kernels ran at the dispatcher's rate (~220 us whatever the tap count).
+constexpr int FB_RB = 16, FB_IL = 4;
+
+// grid = (ceil(nc/256), ceil(h/FB_RB), planes)
 __global__ __launch_bounds__(256) void k_fb_blur_h(const uint8_t *__restrict__ gray, int pitch, int64_t plane_stride,
                                                    int h, int w, fb_taps T, const int32_t *__restrict__ cols, int nc,
                                                    float *__restrict__ out)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (i >= nc) return;
-    const int x = cols ? cols[i] : i;
-    const uint8_t *row = gray + (int64_t)blockIdx.z * plane_stride + (int64_t)y * pitch;
-    const int r = T.ksize >> 1;
-    float a = (float)row[x] * T.k[r];
-    for (int k = 1; k <= r; k++)
-        a += ((float)row[fb_reflect101(x - k, w)] + (float)row[fb_reflect101(x + k, w)]) * T.k[r + k];
-    out[((int64_t)blockIdx.z * h + y) * w + x] = a;
-}
-
-// grid = (ceil(nc/256), nr, planes)
-__global__ __launch_bounds__(256) void k_fb_blur_v(const float *__restrict__ in, int h, int w, fb_taps T,
-                                                   const int32_t *__restrict__ cols, int nc,
-                                                   const int32_t *__restrict__ rows, float *__restrict__ out)
-{
+    // the taps are indexed in a loop of run-time length: read from the by-value argument that is a private-memory
+    // (scratch) access per tap; one LDS copy per workgroup instead
+    __shared__ float kk[32];
+    if (threadIdx.x < 32) kk[threadIdx.x] = T.k[threadIdx.x];
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nc) return;
-    const int x = cols ? cols[i] : i, y = rows ? rows[blockIdx.y] : (int)blockIdx.y;
+    const int x = cols ? cols[i] : i;
+    const int r = T.ksize >> 1;
+    const bool interior = x >= r && x + r < w; // no reflection
+    const int y1 = min((int)(blockIdx.y + 1) * FB_RB, h);
+    const uint8_t *plane = gray + (int64_t)blockIdx.z * plane_stride;
+    // FB_IL rows at a time: a thread with one row's three loads in flight left the kernel latency-bound at full occupancy
+    for (int y = blockIdx.y * FB_RB; y < y1; y += FB_IL) {
+        const uint8_t *row[FB_IL];
+        float a[FB_IL];
+#pragma unroll
+        for (int j = 0; j < FB_IL; j++) {
+            row[j] = plane + (int64_t)min(y + j, y1 - 1) * pitch;
+            a[j] = (float)row[j][x] * kk[r];
+        }
+        if (interior) {
+            for (int k = 1; k <= r; k++) {
+                const float kf = kk[r + k];
+#pragma unroll
+                for (int j = 0; j < FB_IL; j++) a[j] += ((float)row[j][x - k] + (float)row[j][x + k]) * kf;
+            }
+        } else {
+            for (int k = 1; k <= r; k++) {
+                const int xl = fb_reflect101(x - k, w), xr = fb_reflect101(x + k, w);
+                const float kf = kk[r + k];
+#pragma unroll
+                for (int j = 0; j < FB_IL; j++) a[j] += ((float)row[j][xl] + (float)row[j][xr]) * kf;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FB_IL; j++)
+            if (y + j < y1) out[((int64_t)blockIdx.z * h + y + j) * w + x] = a[j];
+    }
+}
+
+// grid = (ceil(nc/256), ceil(nr/FB_RB), planes)
+__global__ __launch_bounds__(256) void k_fb_blur_v(const float *__restrict__ in, int h, int w, fb_taps T,
+                                                   const int32_t *__restrict__ cols, int nc,
+                                                   const int32_t *__restrict__ rows, int nr, float *__restrict__ out)
+{
+    __shared__ float kk[32];
+    if (threadIdx.x < 32) kk[threadIdx.x] = T.k[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc) return;
+    const int x = cols ? cols[i] : i;
     const float *img = in + (int64_t)blockIdx.z * h * w;
     const int r = T.ksize >> 1;
-    float a = img[(int64_t)y * w + x] * T.k[r];
-    for (int k = 1; k <= r; k++)
-        a += (img[(int64_t)fb_reflect101(y - k, h) * w + x] + img[(int64_t)fb_reflect101(y + k, h) * w + x]) * T.k[r + k];
-    out[((int64_t)blockIdx.z * h + y) * w + x] = a;
+    const int j1 = min((int)(blockIdx.y + 1) * FB_RB, nr);
+    for (int j0 = blockIdx.y * FB_RB; j0 < j1; j0 += FB_IL) {
+        int y[FB_IL];
+        float a[FB_IL];
+        bool inner = true;
+#pragma unroll
+        for (int j = 0; j < FB_IL; j++) {
+            const int jj = min(j0 + j, j1 - 1);
+            y[j] = rows ? rows[jj] : jj;
+            inner = inner && y[j] >= r && y[j] + r < h;
+            a[j] = img[(int64_t)y[j] * w + x] * kk[r];
+        }
+        if (inner) {
+            for (int k = 1; k <= r; k++) {
+                const float kf = kk[r + k];
+#pragma unroll
+                for (int j = 0; j < FB_IL; j++) {
+                    const float *c = img + (int64_t)y[j] * w + x;
+                    a[j] += (c[-(int64_t)k * w] + c[(int64_t)k * w]) * kf;
+                }
+            }
+        } else {
+            for (int k = 1; k <= r; k++) {
+                const float kf = kk[r + k];
+#pragma unroll
+                for (int j = 0; j < FB_IL; j++)
+                    a[j] += (img[(int64_t)fb_reflect101(y[j] - k, h) * w + x] + img[(int64_t)fb_reflect101(y[j] + k, h) * w + x]) * kf;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FB_IL; j++)
+            if (j0 + j < j1) out[((int64_t)blockIdx.z * h + y[j]) * w + x] = a[j];
+    }
 }
 
 // ---- cv2.resize INTER_LINEAR on float data with CN interleaved channels; result times `mul` --------
 // mode 0: bilinear with host-built tables; mode 1: exact 2x decimation (INTER_AREA fast path)
-// grid = (ceil(dw/256), dh, images)
+// grid = (ceil(dw/256), ceil(dh/FB_RB), images)
 template <int CN>
 __global__ __launch_bounds__(256) void k_fb_resize(const float *__restrict__ src, int sh, int sw, float *__restrict__ dst,
                                                    int dh, int dw, const int32_t *__restrict__ xofs,
                                                    const float *__restrict__ xa, const int32_t *__restrict__ yofs,
                                                    const float *__restrict__ yb, int mode, float mul, int apply_mul)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= dw) return;
     const float *s = src + (int64_t)blockIdx.z * sh * sw * CN;
-    float *d = dst + (((int64_t)blockIdx.z * dh + y) * dw + x) * CN;
+    const int yend = min((int)(blockIdx.y + 1) * FB_RB, dh);
     if (mode == 1) {
+#pragma unroll 4
+        for (int y = blockIdx.y * FB_RB; y < yend; y++) {
+            float *d = dst + (((int64_t)blockIdx.z * dh + y) * dw + x) * CN;
 #pragma unroll
-        for (int c = 0; c < CN; c++) {
-            const float *p = s + ((int64_t)(2 * y) * sw + 2 * x) * CN + c;
-            float v = (p[0] + p[CN] + p[(int64_t)sw * CN] + p[(int64_t)sw * CN + CN]) * 0.25f;
-            if (apply_mul) v *= mul;
-            d[c] = v;
+            for (int c = 0; c < CN; c++) {
+                const float *p = s + ((int64_t)(2 * y) * sw + 2 * x) * CN + c;
+                float v = (p[0] + p[CN] + p[(int64_t)sw * CN] + p[(int64_t)sw * CN + CN]) * 0.25f;
+                if (apply_mul) v *= mul;
+                d[c] = v;
+            }
         }
         return;
     }
     const int x0 = xofs[x], x1 = min(x0 + 1, sw - 1);
-    const int y0 = min(max(yofs[y], 0), sh - 1), y1 = min(max(yofs[y] + 1, 0), sh - 1);
-    const float a0 = xa[2 * x], a1 = xa[2 * x + 1], b0 = yb[2 * y], b1 = yb[2 * y + 1];
+    const float a0 = xa[2 * x], a1 = xa[2 * x + 1];
+#pragma unroll 4
+    for (int y = blockIdx.y * FB_RB; y < yend; y++) {
+        float *d = dst + (((int64_t)blockIdx.z * dh + y) * dw + x) * CN;
+        const int y0 = min(max(yofs[y], 0), sh - 1), y1 = min(max(yofs[y] + 1, 0), sh - 1);
+        const float b0 = yb[2 * y], b1 = yb[2 * y + 1];
 #pragma unroll
-    for (int c = 0; c < CN; c++) {
-        const float r0 = s[((int64_t)y0 * sw + x0) * CN + c] * a0 + s[((int64_t)y0 * sw + x1) * CN + c] * a1;
-        const float r1 = s[((int64_t)y1 * sw + x0) * CN + c] * a0 + s[((int64_t)y1 * sw + x1) * CN + c] * a1;
-        float v = r0 * b0 + r1 * b1;
-        if (apply_mul) v *= mul;
-        d[c] = v;
+        for (int c = 0; c < CN; c++) {
+            const float r0 = s[((int64_t)y0 * sw + x0) * CN + c] * a0 + s[((int64_t)y0 * sw + x1) * CN + c] * a1;
+            const float r1 = s[((int64_t)y1 * sw + x0) * CN + c] * a0 + s[((int64_t)y1 * sw + x1) * CN + c] * a1;
+            float v = r0 * b0 + r1 * b1;
+            if (apply_mul) v *= mul;
+            d[c] = v;
+        }
     }
 }
 
@@ -110,62 +185,150 @@ __global__ __launch_bounds__(256) void k_fb_resize(const float *__restrict__ src
 // Tile of PE_TY rows x PE_TX columns per workgroup: the vertical pass (float) fills LDS for the tile's
 // columns plus a 5-column replicated halo, the horizontal pass (double accumulators) reads it back.
 constexpr int PE_TX = 64, PE_TY = 4, PE_N = 5;
+constexpr int PE_TILES = 8; // consecutive row tiles per workgroup (fewer, longer workgroups: see FB_RB)
 
-// grid = (ceil(w/PE_TX), ceil(h/PE_TY), planes), block = 256 (thread = one output pixel)
+// grid = (ceil(w/PE_TX), ceil(h/(PE_TY * PE_TILES)), planes), block = 256 (thread = one output pixel per tile)
 __global__ __launch_bounds__(256) void k_fb_polyexp(const float *__restrict__ in, int h, int w, fb_poly C,
                                                     float *__restrict__ out)
 {
     __shared__ float row[PE_TY][PE_TX + 2 * PE_N][3];
     const float *img = in + (int64_t)blockIdx.z * h * w;
-    const int x0 = blockIdx.x * PE_TX, y0 = blockIdx.y * PE_TY;
+    const int x0 = blockIdx.x * PE_TX;
     const float *g = C.g + PE_N, *xg = C.xg + PE_N, *xxg = C.xxg + PE_N;
-    for (int i = threadIdx.x; i < PE_TY * (PE_TX + 2 * PE_N); i += 256) {
-        const int ty = i / (PE_TX + 2 * PE_N), tx = i - ty * (PE_TX + 2 * PE_N);
-        const int y = y0 + ty;
-        const int x = min(max(x0 + tx - PE_N, 0), w - 1); // the horizontal pass replicates the border triples
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-        if (y < h) {
-            t0 = img[(int64_t)y * w + x] * g[0];
+    const int64_t P = (int64_t)h * w;
+    for (int tile = 0; tile < PE_TILES; tile++) {
+        const int y0 = (blockIdx.y * PE_TILES + tile) * PE_TY;
+        if (y0 >= h) break;
+        if (tile) __syncthreads(); // the previous tile's readers are done
+        for (int i = threadIdx.x; i < PE_TY * (PE_TX + 2 * PE_N); i += 256) {
+            const int ty = i / (PE_TX + 2 * PE_N), tx = i - ty * (PE_TX + 2 * PE_N);
+            const int y = y0 + ty;
+            const int x = min(max(x0 + tx - PE_N, 0), w - 1); // the horizontal pass replicates the border triples
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+            if (y < h) {
+                t0 = img[(int64_t)y * w + x] * g[0];
 #pragma unroll
-            for (int k = 1; k <= PE_N; k++) {
-                const float a = img[(int64_t)max(y - k, 0) * w + x], b = img[(int64_t)min(y + k, h - 1) * w + x];
-                const float p = a + b;
-                t0 = t0 + g[k] * p;
-                t1 = t1 + xg[k] * (b - a);
-                t2 = t2 + xxg[k] * p;
+                for (int k = 1; k <= PE_N; k++) {
+                    const float a = img[(int64_t)max(y - k, 0) * w + x], b = img[(int64_t)min(y + k, h - 1) * w + x];
+                    const float p = a + b;
+                    t0 = t0 + g[k] * p;
+                    t1 = t1 + xg[k] * (b - a);
+                    t2 = t2 + xxg[k] * p;
+                }
             }
+            row[ty][tx][0] = t0; row[ty][tx][1] = t1; row[ty][tx][2] = t2;
         }
-        row[ty][tx][0] = t0; row[ty][tx][1] = t1; row[ty][tx][2] = t2;
-    }
-    __syncthreads();
-    const int ty = threadIdx.x / PE_TX, tx = threadIdx.x % PE_TX;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= w || y >= h) return;
-    const float(*r)[3] = &row[ty][tx + PE_N];
-    double b1 = r[0][0] * g[0], b2 = 0, b3 = r[0][1] * g[0], b4 = 0, b5 = r[0][2] * g[0], b6 = 0;
+        __syncthreads();
+        const int ty = threadIdx.x / PE_TX, tx = threadIdx.x % PE_TX;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        const float(*r)[3] = &row[ty][tx + PE_N];
+        double b1 = r[0][0] * g[0], b2 = 0, b3 = r[0][1] * g[0], b4 = 0, b5 = r[0][2] * g[0], b6 = 0;
 #pragma unroll
-    for (int k = 1; k <= PE_N; k++) {
-        const double tg = r[k][0] + r[-k][0];
-        b1 += tg * g[k];
-        b4 += tg * xxg[k];
-        b2 += (r[k][0] - r[-k][0]) * xg[k];
-        b3 += (r[k][1] + r[-k][1]) * g[k];
-        b6 += (r[k][1] - r[-k][1]) * xg[k];
-        b5 += (r[k][2] + r[-k][2]) * g[k];
+        for (int k = 1; k <= PE_N; k++) {
+            const double tg = r[k][0] + r[-k][0];
+            b1 += tg * g[k];
+            b4 += tg * xxg[k];
+            b2 += (r[k][0] - r[-k][0]) * xg[k];
+            b3 += (r[k][1] + r[-k][1]) * g[k];
+            b6 += (r[k][1] - r[-k][1]) * xg[k];
+            b5 += (r[k][2] + r[-k][2]) * g[k];
+        }
+        // the five coefficients go to five PLANES (channel-major): the flow iteration reads them one column per lane, and
+        // planar the loads of a row are contiguous and the bilinear corners x1, x1 + 1 are one 8-byte load
+        float *d = out + (int64_t)blockIdx.z * P * 5 + (int64_t)y * w + x;
+        d[P] = (float)(b2 * C.ig11);
+        d[0] = (float)(b3 * C.ig11);
+        d[3 * P] = (float)(b1 * C.ig03 + b4 * C.ig33);
+        d[2 * P] = (float)(b1 * C.ig03 + b5 * C.ig33);
+        d[4 * P] = (float)(b6 * C.ig55);
     }
-    float *d = out + (((int64_t)blockIdx.z * h + y) * w + x) * 5;
-    d[1] = (float)(b2 * C.ig11);
-    d[0] = (float)(b3 * C.ig11);
-    d[3] = (float)(b1 * C.ig03 + b4 * C.ig33);
-    d[2] = (float)(b1 * C.ig03 + b5 * C.ig33);
-    d[4] = (float)(b6 * C.ig55);
 }
 
 // ---- FarnebackUpdateMatrices: pair p uses expansions of planes p and p + 1 -------------------------
-// grid = (ceil(w/256), h, pairs)
 // SRC: where the flow comes from.  0 = the level's flow field; 1 = the coarser level's flow, resized
 // (INTER_LINEAR, the k_fb_resize<2> arithmetic) and doubled on the fly — the first rebuild of a level is its
 // only reader, so the upsampled field is never written; 2 = zero (coarsest level).
+template <int SRC>
+__device__ __forceinline__ void fb_flow_at(const float *__restrict__ flow /* the pair's field */, int w, int x, int y, int ch,
+                                           int cw, const int32_t *__restrict__ xofs, const float *__restrict__ xa,
+                                           const int32_t *__restrict__ yofs, const float *__restrict__ yb, float mul,
+                                           float &dx, float &dy)
+{
+    dx = 0.f;
+    dy = 0.f;
+    if (SRC == 0) {
+        const float2 f = *reinterpret_cast<const float2 *>(flow + ((int64_t)y * w + x) * 2);
+        dx = f.x;
+        dy = f.y;
+    } else if (SRC == 1) {
+        const int x0 = xofs[x], x1c = min(x0 + 1, cw - 1);
+        const int y0 = min(max(yofs[y], 0), ch - 1), y1c = min(max(yofs[y] + 1, 0), ch - 1);
+        const float a0 = xa[2 * x], a1 = xa[2 * x + 1], b0 = yb[2 * y], b1 = yb[2 * y + 1];
+        float v[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float q0 = flow[((int64_t)y0 * cw + x0) * 2 + c] * a0 + flow[((int64_t)y0 * cw + x1c) * 2 + c] * a1;
+            const float q1 = flow[((int64_t)y1c * cw + x0) * 2 + c] * a0 + flow[((int64_t)y1c * cw + x1c) * 2 + c] * a1;
+            v[c] = (q0 * b0 + q1 * b1) * mul;
+        }
+        dx = v[0];
+        dy = v[1];
+    }
+}
+
+// the five products of pixel (x, y) under the displacement (dx, dy): R0 / R1 = the expansions of the pair's two planes,
+// five coefficient planes of P = h * w floats each
+struct __attribute__((packed, aligned(4))) fb_f2 { float a, b; }; // two adjacent floats, 4-byte aligned: one global_load_dwordx2
+
+__device__ __forceinline__ void fb_products(const float *__restrict__ R0, const float *__restrict__ R1, int h, int w, int x,
+                                            int y, float dx, float dy, float m[5])
+{
+    const int64_t P = (int64_t)h * w;
+    const float *r0 = R0 + (int64_t)y * w + x;
+    const float r00 = r0[0], r01 = r0[P], r02 = r0[2 * P], r03 = r0[3 * P], r04 = r0[4 * P];
+    float fx = x + dx, fy = y + dy;
+    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1; fy -= y1;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        const float *p = R1 + (int64_t)y1 * w + x1;
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        float v[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const fb_f2 t = *reinterpret_cast<const fb_f2 *>(p + c * P), b = *reinterpret_cast<const fb_f2 *>(p + c * P + w);
+            v[c] = a00 * t.a + a01 * t.b + a10 * b.a + a11 * b.b;
+        }
+        r2 = v[0]; r3 = v[1];
+        r4 = (r02 + v[2]) * 0.5f;
+        r5 = (r03 + v[3]) * 0.5f;
+        r6 = (r04 + v[4]) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = r02; r5 = r03; r6 = r04 * 0.5f;
+    }
+    r2 = (r00 - r2) * 0.5f;
+    r3 = (r01 - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
+        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        const float scale = (x < 5 ? border[x] : 1.f) * (x >= w - 5 ? border[w - x - 1] : 1.f) *
+                            (y < 5 ? border[y] : 1.f) * (y >= h - 5 ? border[h - y - 1] : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
+}
+
+constexpr int BS_M = 7; // the 15x15 box of FarnebackUpdateFlow_Blur (winsize 15)
+
+#ifdef VQA_AB_VARIANTS // rounds 2-3: products written to HBM by one kernel, box-summed and solved by a second (lab build)
+// grid = (ceil(w/256), h, pairs)
 template <int SRC>
 __global__ __launch_bounds__(256) void k_fb_update(const float *__restrict__ R, const float *__restrict__ flow, int h,
                                                    int w, float *__restrict__ M, int ch, int cw,
@@ -177,63 +340,13 @@ __global__ __launch_bounds__(256) void k_fb_update(const float *__restrict__ R, 
     if (x >= w) return;
     const int64_t P = (int64_t)h * w;
     const float *R0 = R + (int64_t)blockIdx.z * P * 5, *R1 = R0 + P * 5;
-    const int64_t pix = (int64_t)blockIdx.z * P + (int64_t)y * w + x;
-    const float *r0 = R0 + ((int64_t)y * w + x) * 5;
-    float dx = 0.f, dy = 0.f;
-    if (SRC == 0) {
-        dx = flow[pix * 2];
-        dy = flow[pix * 2 + 1];
-    } else if (SRC == 1) {
-        const float *s = flow + (int64_t)blockIdx.z * ch * cw * 2;
-        const int x0 = xofs[x], x1c = min(x0 + 1, cw - 1);
-        const int y0 = min(max(yofs[y], 0), ch - 1), y1c = min(max(yofs[y] + 1, 0), ch - 1);
-        const float a0 = xa[2 * x], a1 = xa[2 * x + 1], b0 = yb[2 * y], b1 = yb[2 * y + 1];
-        float v[2];
+    const float *fp = SRC == 0 ? flow + (int64_t)blockIdx.z * P * 2 : SRC == 1 ? flow + (int64_t)blockIdx.z * ch * cw * 2 : nullptr;
+    float dx, dy, m[5];
+    fb_flow_at<SRC>(fp, w, x, y, ch, cw, xofs, xa, yofs, yb, mul, dx, dy);
+    fb_products(R0, R1, h, w, x, y, dx, dy, m);
+    float *o = M + ((int64_t)blockIdx.z * P + (int64_t)y * w + x) * 5;
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const float q0 = s[((int64_t)y0 * cw + x0) * 2 + c] * a0 + s[((int64_t)y0 * cw + x1c) * 2 + c] * a1;
-            const float q1 = s[((int64_t)y1c * cw + x0) * 2 + c] * a0 + s[((int64_t)y1c * cw + x1c) * 2 + c] * a1;
-            v[c] = (q0 * b0 + q1 * b1) * mul;
-        }
-        dx = v[0];
-        dy = v[1];
-    }
-    float fx = x + dx, fy = y + dy;
-    const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-    float r2, r3, r4, r5, r6;
-    fx -= x1; fy -= y1;
-    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        const int64_t step1 = (int64_t)w * 5;
-        const float *p = R1 + (int64_t)y1 * step1 + (int64_t)x1 * 5;
-        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        r2 = a00 * p[0] + a01 * p[5] + a10 * p[step1] + a11 * p[step1 + 5];
-        r3 = a00 * p[1] + a01 * p[6] + a10 * p[step1 + 1] + a11 * p[step1 + 6];
-        r4 = a00 * p[2] + a01 * p[7] + a10 * p[step1 + 2] + a11 * p[step1 + 7];
-        r5 = a00 * p[3] + a01 * p[8] + a10 * p[step1 + 3] + a11 * p[step1 + 8];
-        r6 = a00 * p[4] + a01 * p[9] + a10 * p[step1 + 4] + a11 * p[step1 + 9];
-        r4 = (r0[2] + r4) * 0.5f;
-        r5 = (r0[3] + r5) * 0.5f;
-        r6 = (r0[4] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = r0[2]; r5 = r0[3]; r6 = r0[4] * 0.5f;
-    }
-    r2 = (r0[0] - r2) * 0.5f;
-    r3 = (r0[1] - r3) * 0.5f;
-    r2 += r4 * dy + r6 * dx;
-    r3 += r6 * dy + r5 * dx;
-    if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
-        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
-        const float scale = (x < 5 ? border[x] : 1.f) * (x >= w - 5 ? border[w - x - 1] : 1.f) *
-                            (y < 5 ? border[y] : 1.f) * (y >= h - 5 ? border[h - y - 1] : 1.f);
-        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    }
-    float *m = M + pix * 5;
-    m[0] = r4 * r4 + r6 * r6;
-    m[1] = (r4 + r5) * r6;
-    m[2] = r5 * r5 + r6 * r6;
-    m[3] = r4 * r2 + r6 * r3;
-    m[4] = r6 * r2 + r5 * r3;
+    for (int c = 0; c < 5; c++) o[c] = m[c];
 }
 
 // ---- FarnebackUpdateFlow_Blur: 15x15 box sums of the products + 2x2 solve --------------------------
@@ -242,7 +355,7 @@ __global__ __launch_bounds__(256) void k_fb_update(const float *__restrict__ R, 
 // in double, stage 2 slides a 15-high window down every (column, channel), stage 3 scales and solves.
 // Sums are carried in double as in OpenCV; the sliding order differs from the oracle's tap order only at
 // the 1e-16 level, far below what the regularised solve can amplify.
-constexpr int BS_TX = 32, BS_TY = 16, BS_M = 7;
+constexpr int BS_TX = 32, BS_TY = 16;
 constexpr int BS_IW = BS_TX + 2 * BS_M, BS_IH = BS_TY + 2 * BS_M;
 
 constexpr int BS_NT = 1024; // 16 waves share one 66 KB tile: the global->LDS fill and the solve dominate, both want threads
@@ -317,6 +430,145 @@ __global__ __launch_bounds__(BS_NT) void k_fb_blur_solve(const float *__restrict
     }
 }
 
+#endif // VQA_AB_VARIANTS
+
+// ---- one flow iteration, fused: FarnebackUpdateMatrices + FarnebackUpdateFlow_Blur -----------------------------
+// Round 4.  The two-kernel form above wrote the five products (20 B/pixel) to HBM and read them back with a 2.7x
+// halo factor, and its sliding sums ran on 15 % of a workgroup's threads.  Here a workgroup owns FI_NT columns
+// (FI_OUT = FI_NT - 14 output columns + the 7-column halo either side) of a row strip and MARCHES down it:
+//   * thread = one column: it forms the products of the entering row (y + 7) in registers, keeps the last 16 rows of
+//     them in a register ring, and carries OpenCV's running column sum  vsum += float(M[y+7] - M[y-8])  in double -
+//     the same float difference, in the same order, as optflowgf.cpp / oracle fb_blur_solve; with one strip per frame
+//     (ns = 1) the column sums are the oracle's bit for bit, drift of the float differences included; a lower strip
+//     starts from the plain sum of its first 15 rows;
+//   * two rows of column sums go through LDS per step; lane pair (2j, 2j+1) takes the output columns 2j, 2j+1 of one
+//     row each: 16 doubles -> the 15-column window sum of the first and, sliding by one, of the second (8 ds_read_b128
+//     per channel for two outputs); then the regularised 2x2 solve and the flow store.
+// The horizontal window is summed left to right per output, not slid along the whole row as OpenCV does: that
+// differs at the 1e-16 level only.  Products are never written: per pixel the iteration reads 20 B (R0) + 20 B (R1,
+// gathered) + 8 B (flow) and writes 8 B.
+// grid = (ncb * ns, pairs), block = FI_NT; QS = rows per strip, a multiple of 16 (static ring slots)
+constexpr int FI_NT = 256, FI_OUT = FI_NT - 14;
+#ifndef FB_PROBE
+#define FB_PROBE 0 // measurement builds only (scripts/build_probes.sh FB_PROBE 1 2): 1 = no horizontal phase, 2 = no products
+#endif
+constexpr int FI_LD = 272; // doubles per LDS row: 2176 B = 8 * 256 + 128, so the two rows of a lane pair sit 32 banks apart
+
+template <int SRC>
+__global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, const float *__restrict__ fin, int h, int w,
+                                                   float *__restrict__ fout, int ch, int cw,
+                                                   const int32_t *__restrict__ xofs, const float *__restrict__ xa,
+                                                   const int32_t *__restrict__ yofs, const float *__restrict__ yb, float mul,
+                                                   int ncb, int QS)
+{
+    __shared__ double vs[5][2][FI_LD];
+    const int t = threadIdx.x;
+    const int cb = blockIdx.x % ncb, sb = blockIdx.x / ncb;
+    const int x0 = cb * FI_OUT, ys = sb * QS;
+    const int yend = min(ys + QS, h);
+    const int64_t P = (int64_t)h * w;
+    const float *R0 = R + (int64_t)blockIdx.y * P * 5, *R1 = R0 + P * 5;
+    const float *fp = SRC == 0 ? fin + (int64_t)blockIdx.y * P * 2 : SRC == 1 ? fin + (int64_t)blockIdx.y * ch * cw * 2 : nullptr;
+    float *fo = fout + (int64_t)blockIdx.y * P * 2;
+    const int xx = min(max(x0 - BS_M + t, 0), w - 1); // replicated border: the clamped column's products ARE the border's
+    float ring[16][5];
+#pragma unroll
+    for (int s = 0; s < 16; s++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) ring[s][c] = 0.f;
+    double vsum[5] = {0., 0., 0., 0., 0.};
+    // horizontal role: output columns k0, k0 + 1 (relative to x0) of row (t & 1) of the step
+    const int k0 = t & ~1, hrow = t & 1;
+    const double *vrow = &vs[0][hrow][k0];
+    const bool out0 = k0 < FI_OUT && x0 + k0 < w, out1 = k0 + 1 < FI_OUT && x0 + k0 + 1 < w;
+
+    // Row gi of the strip's march: output row y = ys - 16 + gi, entering product row rho = y + 7 (clamped = replicated).
+    // gi = 0 is a dummy (keeps steps of two rows aligned with the 16-slot ring), gi = 1..15 prime the column sums with
+    // the rows ys-8 .. ys+6 (the ring is zero there, so the difference form adds the plain values), gi >= 16 emit.
+    // The displacement of a step's two rows is fetched one step ahead: the gathers of R1 depend on it, and the two
+    // dependent round trips per step were the kernel's critical path.
+    auto row_of = [&](int y) { return min(max(y + BS_M, 0), h - 1); };
+    float dxn[2], dyn[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) fb_flow_at<SRC>(fp, w, xx, row_of(ys - 16 + q), ch, cw, xofs, xa, yofs, yb, mul, dxn[q], dyn[q]);
+    for (int base = 0;; base += 16) {
+        const int yb0 = ys - 16 + base;
+        if (yb0 >= yend) break;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const float dx0 = dxn[0], dy0 = dyn[0], dx1 = dxn[1], dy1 = dyn[1];
+            float cur[2][5];
+#if FB_PROBE == 2
+            for (int c = 0; c < 5; c++) { cur[0][c] = dx0 + c; cur[1][c] = dy1 + dx1 + dy0 - c; }
+#else
+            fb_products(R0, R1, h, w, xx, row_of(yb0 + i), dx0, dy0, cur[0]);
+            fb_products(R0, R1, h, w, xx, row_of(yb0 + i + 1), dx1, dy1, cur[1]);
+#endif
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                fb_flow_at<SRC>(fp, w, xx, row_of(yb0 + i + 2 + q), ch, cw, xofs, xa, yofs, yb, mul, dxn[q], dyn[q]);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int y = yb0 + i + q, rho = y + BS_M;
+                const bool dummy = i + q == 0 && base == 0;
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    float add = cur[q][c] - ring[(i + q + 8) & 15][c]; // leaving row y - 8 (zero while priming)
+                    // top of the frame, OpenCV's start: vsum = float(M[0] * 9) + M[1] + .. + M[6]; the rows -8 .. -1 are M[0]
+                    if (y < 0) add = rho == -8 ? cur[q][c] * 9.f : (rho <= 0 ? 0.f : cur[q][c]);
+                    if (dummy) add = 0.f;
+                    vsum[c] += (double)add;
+                    ring[(i + q + 7) & 15][c] = dummy ? 0.f : cur[q][c];
+                    vs[c][q][t] = vsum[c];
+                }
+            }
+            if (base > 0) {
+                __syncthreads();
+                const int yo = yb0 + i + hrow;
+#if FB_PROBE == 1
+                if (yo < yend && out0) {
+                    float *f = fo + ((int64_t)yo * w + x0 + k0) * 2;
+                    f[0] = (float)vrow[0]; f[1] = (float)vrow[FI_LD]; f[2] = (float)vrow[1]; f[3] = (float)vrow[FI_LD + 1];
+                }
+#else
+                if (yo < yend && out0) {
+                    double s0[5], s1[5];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        const double2 *p = reinterpret_cast<const double2 *>(vrow + (size_t)c * 2 * FI_LD);
+                        double2 v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) v[k] = p[k];
+                        double a = v[0].x;
+                        a += v[0].y;
+#pragma unroll
+                        for (int k = 1; k < 7; k++) { a += v[k].x; a += v[k].y; }
+                        a += v[7].x;
+                        s0[c] = a;
+                        s1[c] = a + (v[7].y - v[0].x);
+                    }
+                    const double scale = 1. / 225.;
+                    float *f = fo + ((int64_t)yo * w + x0 + k0) * 2;
+                    {
+                        const double g11 = s0[0] * scale, g12 = s0[1] * scale, g22 = s0[2] * scale, h1 = s0[3] * scale, h2 = s0[4] * scale;
+                        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                        f[0] = (float)((g11 * h2 - g12 * h1) * idet);
+                        f[1] = (float)((g22 * h1 - g12 * h2) * idet);
+                    }
+                    if (out1) {
+                        const double g11 = s1[0] * scale, g12 = s1[1] * scale, g22 = s1[2] * scale, h1 = s1[3] * scale, h2 = s1[4] * scale;
+                        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                        f[2] = (float)((g11 * h2 - g12 * h1) * idet);
+                        f[3] = (float)((g22 * h1 - g12 * h2) * idet);
+                    }
+                }
+#endif
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // ---- mean magnitude --------------------------------------------------------------------------------
 // grid = (FB_MAG_BLOCKS, pairs); partials[pair][block] then a fixed-order finalize (bit-reproducible)
 constexpr int FB_MAG_BLOCKS = 64;
@@ -348,15 +600,16 @@ void launch_fb_blur(hipStream_t st, const uint8_t *gray, int pitch, int64_t plan
 {
     if (!cols) nc = w;
     if (!rows) nr = h;
-    hipLaunchKernelGGL(k_fb_blur_h, dim3((nc + 255) / 256, h, planes), dim3(256), 0, st, gray, pitch, plane_stride, h, w, T,
-                       cols, nc, tmp);
-    hipLaunchKernelGGL(k_fb_blur_v, dim3((nc + 255) / 256, nr, planes), dim3(256), 0, st, tmp, h, w, T, cols, nc, rows, out);
+    hipLaunchKernelGGL(k_fb_blur_h, dim3((nc + 255) / 256, (h + FB_RB - 1) / FB_RB, planes), dim3(256), 0, st, gray, pitch,
+                       plane_stride, h, w, T, cols, nc, tmp);
+    hipLaunchKernelGGL(k_fb_blur_v, dim3((nc + 255) / 256, (nr + FB_RB - 1) / FB_RB, planes), dim3(256), 0, st, tmp, h, w, T, cols,
+                       nc, rows, nr, out);
 }
 
 void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, float *dst, int dh, int dw, int images,
                       const fb_resize_tabs &T, float mul, bool apply_mul)
 {
-    dim3 grid((dw + 255) / 256, dh, images);
+    dim3 grid((dw + 255) / 256, (dh + FB_RB - 1) / FB_RB, images);
     if (cn == 1)
         hipLaunchKernelGGL(k_fb_resize<1>, grid, dim3(256), 0, st, src, sh, sw, dst, dh, dw, T.xofs, T.xa, T.yofs, T.yb,
                            T.mode, mul, (int)apply_mul);
@@ -367,10 +620,11 @@ void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, 
 
 void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out)
 {
-    dim3 grid((w + PE_TX - 1) / PE_TX, (h + PE_TY - 1) / PE_TY, planes);
+    dim3 grid((w + PE_TX - 1) / PE_TX, (h + PE_TY * PE_TILES - 1) / (PE_TY * PE_TILES), planes);
     hipLaunchKernelGGL(k_fb_polyexp, grid, dim3(256), 0, st, in, h, w, C, out);
 }
 
+#ifdef VQA_AB_VARIANTS
 void launch_fb_update(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *M)
 {
     dim3 grid((w + 255) / 256, h, pairs);
@@ -393,6 +647,35 @@ void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int 
 {
     dim3 grid((w + BS_TX - 1) / BS_TX, (h + BS_TY - 1) / BS_TY, pairs);
     hipLaunchKernelGGL(k_fb_blur_solve, grid, dim3(BS_NT), 0, st, M, h, w, flow);
+}
+
+#endif
+
+// One fused iteration: flow_out = solve(box15x15(products(R, flow_in))).  flow_in: coarse != nullptr -> the coarser
+// level's ch x cw field, upsampled and scaled by mul in flight (first iteration of a level); else `flow` (same size);
+// both null -> zero flow (coarsest level).  flow_out must not alias the input: neighbours read it while it is written.
+void launch_fb_iter(hipStream_t st, const float *R, const float *flow, const float *coarse, int ch, int cw,
+                    const fb_resize_tabs &T, float mul, int pairs, int h, int w, float *flow_out)
+{
+    const int ncb = (w + FI_OUT - 1) / FI_OUT;
+    // strips: one per frame when that fills the chip (the column sums then follow OpenCV's whole-frame order exactly),
+    // more (>= 32 rows each: a strip re-forms 15 rows of products to prime its sums) when a launch would otherwise have
+    // fewer than ~3 workgroups per CU - a workgroup's march is a chain of dependent steps, ~3 us per two rows
+    int ns = (int)((768 + (long long)ncb * pairs - 1) / ((long long)ncb * pairs));
+    const int cap = h / 32 < 1 ? 1 : h / 32;
+    ns = ns < 1 ? 1 : (ns > cap ? cap : ns);
+    const int QS = ((h + ns - 1) / ns + 15) / 16 * 16;
+    ns = (h + QS - 1) / QS;
+    dim3 grid(ncb * ns, pairs);
+    if (coarse)
+        hipLaunchKernelGGL(k_fb_iter<1>, grid, dim3(FI_NT), 0, st, R, coarse, h, w, flow_out, ch, cw, T.xofs, T.xa, T.yofs, T.yb,
+                           mul, ncb, QS);
+    else if (flow)
+        hipLaunchKernelGGL(k_fb_iter<0>, grid, dim3(FI_NT), 0, st, R, flow, h, w, flow_out, 0, 0, nullptr, nullptr, nullptr,
+                           nullptr, 0.f, ncb, QS);
+    else
+        hipLaunchKernelGGL(k_fb_iter<2>, grid, dim3(FI_NT), 0, st, R, nullptr, h, w, flow_out, 0, 0, nullptr, nullptr, nullptr,
+                           nullptr, 0.f, ncb, QS);
 }
 
 int fb_mag_blocks() { return FB_MAG_BLOCKS; }

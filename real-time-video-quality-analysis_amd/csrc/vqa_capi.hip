@@ -396,21 +396,31 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
     levels = k;
     const fb_poly PC = fb_poly_consts();
     const size_t P = (size_t)h * w;
-    // per pair ~72 B/pixel of scratch (planes: blur tmp 4 + blurred 4 + level image 4 + expansion 20; pairs:
-    // products 20 + two flow fields 16); keep a chunk under ~3 GiB
-    int mc = (int)((3ull << 30) / (72 * P));
+    // per pair ~52 B/pixel of scratch (planes: blur tmp 4 + blurred 4 + level image 4 + expansion 20; pairs: two
+    // flow fields 16; + 20 for the products of the lab build's two-kernel form); a chunk stays under ~12 GiB of the
+    // 288: a 64-frame 1080p batch is ONE chunk (round 3's 3 GiB cut it into 21 + 21 + 21 + 1 pairs, and the
+    // one-pair tail ran fifty launches on an empty chip)
+#ifdef VQA_AB_VARIANTS
+    const bool two_kernel = ab_knob("VQA_FB_VARIANT", 0) == 1;
+#else
+    const bool two_kernel = false;
+#endif
+    int mc = (int)((12ull << 30) / ((two_kernel ? 72 : 52) * P));
     mc = mc < 1 ? 1 : (mc > n ? n : mc);
     int rc;
     if ((rc = ensure(c, c->fb_tmp, sizeof(float) * P * (mc + 1)))) return rc;
     if ((rc = ensure(c, c->fb_blur, sizeof(float) * P * (mc + 1)))) return rc;
     if ((rc = ensure(c, c->fb_img, sizeof(float) * P * (mc + 1)))) return rc;
     if ((rc = ensure(c, c->fb_R, sizeof(float) * 5 * P * (mc + 1)))) return rc;
-    if ((rc = ensure(c, c->fb_M, sizeof(float) * 5 * P * mc))) return rc;
+    if (two_kernel && (rc = ensure(c, c->fb_M, sizeof(float) * 5 * P * mc))) return rc;
     if ((rc = ensure(c, c->fb_flow0, sizeof(float) * 2 * P * mc))) return rc;
     if ((rc = ensure(c, c->fb_flow1, sizeof(float) * 2 * P * mc))) return rc;
     if ((rc = ensure(c, c->fb_part, sizeof(double) * fb_mag_blocks() * mc))) return rc;
     float *tmp = (float *)c->fb_tmp.p, *blur = (float *)c->fb_blur.p, *img = (float *)c->fb_img.p;
-    float *R = (float *)c->fb_R.p, *M = (float *)c->fb_M.p;
+    float *R = (float *)c->fb_R.p;
+#ifdef VQA_AB_VARIANTS
+    float *M = (float *)c->fb_M.p;
+#endif
     float *flow = (float *)c->fb_flow0.p, *prev_flow = (float *)c->fb_flow1.p;
     for (int a = 0; a < n; a += mc) {
         const int pairs = (n - a) < mc ? (n - a) : mc, planes = pairs + 1;
@@ -443,12 +453,33 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
                                tmp, blur);
             }
             launch_fb_polyexp(st, level_img, planes, lh, lw, PC, R);
-            launch_fb_update_first(st, R, coarsest ? nullptr : prev_flow, ph, pw, TF, (float)(1. / pyr_scale), pairs, lh, lw, M);
-            for (int i = 0; i < iters; i++) {
-                launch_fb_blur_solve(st, M, pairs, lh, lw, flow);
-                if (i < iters - 1) launch_fb_update(st, R, flow, pairs, lh, lw, M);
+#ifdef VQA_AB_VARIANTS
+            if (two_kernel) {
+                launch_fb_update_first(st, R, coarsest ? nullptr : prev_flow, ph, pw, TF, (float)(1. / pyr_scale), pairs, lh, lw, M);
+                for (int i = 0; i < iters; i++) {
+                    launch_fb_blur_solve(st, M, pairs, lh, lw, flow);
+                    if (i < iters - 1) launch_fb_update(st, R, flow, pairs, lh, lw, M);
+                }
+                float *t = flow; flow = prev_flow; prev_flow = t; // prev_flow = this level's result
+            } else
+#endif
+            {
+                // The coarser level's result (prev_flow) is upsampled and doubled into `flow` by the resize kernel (8 B/pixel
+                // written once per level: forming it inside the first iteration instead cost that iteration 70 % more time
+                // than the write - the eight dependent loads per row sit on the march's critical path); the iterations then
+                // ping-pong between the two buffers, and prev_flow ends up naming this level's result.
+                const float *in = nullptr;
+                if (!coarsest) {
+                    launch_fb_resize(st, prev_flow, ph, pw, 2, flow, lh, lw, pairs, TF, (float)(1. / pyr_scale), true);
+                    float *t = flow; flow = prev_flow; prev_flow = t;
+                    in = prev_flow;
+                }
+                for (int i = 0; i < iters; i++) {
+                    launch_fb_iter(st, R, in, nullptr, 0, 0, TF, 0.f, pairs, lh, lw, flow);
+                    float *t = flow; flow = prev_flow; prev_flow = t;
+                    in = prev_flow;
+                }
             }
-            float *t = flow; flow = prev_flow; prev_flow = t; // prev_flow = this level's result
             pw = lw; ph = lh;
         }
         launch_fb_mag(st, prev_flow, pairs, h, w, (double *)c->fb_part.p, a > 0 || first_has_prev, res + a);
