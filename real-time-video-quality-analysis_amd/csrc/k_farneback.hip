@@ -181,6 +181,148 @@ __global__ __launch_bounds__(256) void k_fb_resize(const float *__restrict__ src
     }
 }
 
+// ---- the level image in one kernel: Gaussian blur of the u8 plane + cv2.resize to the level ---------------------
+// Round 4.  The three kernels above (blur_h -> tmp, blur_v -> blur, resize -> level image) ran ~0.3 ms per level on a
+// 33-plane 1080p chunk whatever the level, four levels per chunk: thousands of tiny latency-bound launches' worth of
+// work.  Here a workgroup owns a tile of the LEVEL image and forms exactly the blurred samples its pixels read:
+//   S = 2: the four bilinear taps (or the 2x2 mean of an exact halving) of each pixel sit at the sample columns
+//          sx[2X], sx[2X+1] and sample rows sy[2Y], sy[2Y+1] (host tables: clamps applied); a tile is 32 x NSY/2 pixels;
+//   S = 1: the finest level, no resize: one sample per pixel, a tile is 64 x NSY pixels.
+// Stages (all in LDS): A the u8 patch around the tile's samples, addressed by VIRTUAL row / column so that
+// BORDER_REFLECT_101 is resolved once here; B the horizontal pass at the 64 sample columns of every patch row; C the
+// vertical pass at the NSY sample rows; D the resize arithmetic.  Every float expression is the one of
+// k_fb_blur_h / k_fb_blur_v / k_fb_resize<1> in the same order, so the level image is bit-identical to theirs.
+// grid = (ceil(lw / (64/S)), ceil(lh / (NSY/S)), planes), block = 256, dynamic LDS = fb_level_lds(...)
+struct fb_level_args {
+    const uint8_t *gray; int pitch; int64_t plane_stride; int h, w;   // source planes
+    float *out; int lh, lw;                                           // level images, lh x lw floats per plane
+    const int32_t *sx, *sy;                                           // S = 2: sample coordinates, 2 per level column / row
+    const float *xa, *yb; int mode;                                   // S = 2: bilinear weights; mode 1 = 2x2 mean
+    int cap_x, cap_y;                                                 // patch capacity (columns incl. 2r, rows incl. 2r)
+};
+
+static inline size_t fb_level_lds(int cap_x, int cap_y, int nsy)
+{
+    return (size_t)((cap_x + 3) & ~3) * cap_y + sizeof(float) * 64 * cap_y + sizeof(float) * 64 * nsy + sizeof(float) * 32 +
+           sizeof(int) * (64 + nsy);
+}
+
+template <int S, int NSY>
+__global__ __launch_bounds__(256) void k_fb_level(fb_level_args A, fb_taps T)
+{
+    extern __shared__ __align__(16) unsigned char fl_lds[];
+    const int px = (A.cap_x + 3) & ~3;
+    float *hb = reinterpret_cast<float *>(fl_lds);        // [cap_y][64]
+    float *bt = hb + 64 * A.cap_y;                         // [NSY][64]
+    float *kk = bt + 64 * NSY;                             // [32]
+    int *sc = reinterpret_cast<int *>(kk + 32);            // [64] sample columns
+    int *sr = sc + 64;                                     // [NSY] sample rows
+    unsigned char *u8t = reinterpret_cast<unsigned char *>(sr + NSY); // [cap_y][px]
+    const int t = threadIdx.x;
+    const int X0 = blockIdx.x * (64 / S), Y0 = blockIdx.y * (NSY / S);
+    const int r = T.ksize >> 1;
+    if (t < 32) kk[t] = T.k[t];
+    if (t < 64) {
+        if (S == 1) sc[t] = min(X0 + t, A.w - 1);
+        else sc[t] = A.sx[2 * min(X0 + (t >> 1), A.lw - 1) + (t & 1)];
+    }
+    if (t >= 64 && t < 64 + NSY) {
+        const int j = t - 64;
+        if (S == 1) sr[j] = min(Y0 + j, A.h - 1);
+        else sr[j] = A.sy[2 * min(Y0 + (j >> 1), A.lh - 1) + (j & 1)];
+    }
+    __syncthreads();
+    const int xlo = sc[0] - r, ylo = sr[0] - r;
+    const int xspan = sc[63] - sc[0] + 1 + 2 * r, yspan = sr[NSY - 1] - sr[0] + 1 + 2 * r; // <= cap_x, cap_y (host-checked)
+    const uint8_t *plane = A.gray + (int64_t)blockIdx.z * A.plane_stride;
+    // A: the patch, virtual coordinates -> reflected source coordinates.  Eight rows per thread in flight: with one
+    // load per iteration the stage was a chain of 20-80 dependent global round trips per workgroup.
+    for (int vx = t & 63; vx < xspan; vx += 64) {
+        const uint8_t *col = plane + fb_reflect101(xlo + vx, A.w);
+        for (int vy0 = t >> 6; vy0 < yspan; vy0 += 32) {
+            unsigned char v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = col[(int64_t)fb_reflect101(ylo + min(vy0 + 4 * u, yspan - 1), A.h) * A.pitch];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (vy0 + 4 * u < yspan) u8t[(vy0 + 4 * u) * px + vx] = v[u];
+        }
+    }
+    __syncthreads();
+    // B: horizontal pass at the sample columns, every patch row (four rows per thread in flight)
+    {
+        const int i = t & 63;
+        const unsigned char *c0 = u8t + (sc[i] - xlo);
+        for (int vy0 = t >> 6; vy0 < yspan; vy0 += 16) {
+            const unsigned char *c[4];
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                c[u] = c0 + min(vy0 + 4 * u, yspan - 1) * px;
+                a[u] = (float)c[u][0] * kk[r];
+            }
+            for (int k = 1; k <= r; k++) {
+                const float kf = kk[r + k];
+#pragma unroll
+                for (int u = 0; u < 4; u++) a[u] += ((float)c[u][-k] + (float)c[u][k]) * kf;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (vy0 + 4 * u < yspan) hb[(vy0 + 4 * u) * 64 + i] = a[u];
+        }
+    }
+    __syncthreads();
+    // C: vertical pass at the sample rows (four per thread in flight; NSY is a multiple of 16)
+    {
+        const int i = t & 63;
+        for (int j0 = t >> 6; j0 < NSY; j0 += 16) {
+            const float *c[4];
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                c[u] = hb + (sr[j0 + 4 * u] - ylo) * 64 + i;
+                a[u] = c[u][0] * kk[r];
+            }
+            for (int k = 1; k <= r; k++) {
+                const float kf = kk[r + k];
+#pragma unroll
+                for (int u = 0; u < 4; u++) a[u] += (c[u][-64 * k] + c[u][64 * k]) * kf;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 4 * u;
+                if (S == 1) {
+                    const int X = X0 + i, Y = Y0 + j;
+                    if (X < A.lw && Y < A.lh) A.out[((int64_t)blockIdx.z * A.lh + Y) * A.lw + X] = a[u];
+                } else {
+                    bt[j * 64 + i] = a[u];
+                }
+            }
+        }
+    }
+    if (S == 1) return;
+    __syncthreads();
+    // D: cv2.resize on the four samples of each pixel
+    {
+        const int ix = t & 31, X = X0 + ix;
+        for (int jy = t >> 5; jy < NSY / 2; jy += 8) {
+            const int Y = Y0 + jy;
+            if (X >= A.lw || Y >= A.lh) continue;
+            const float *p = bt + (2 * jy) * 64 + 2 * ix;
+            float v;
+            if (A.mode == 1) {
+                v = (p[0] + p[1] + p[64] + p[65]) * 0.25f;
+            } else {
+                const float a0 = A.xa[2 * X], a1 = A.xa[2 * X + 1], b0 = A.yb[2 * Y], b1 = A.yb[2 * Y + 1];
+                const float r0 = p[0] * a0 + p[1] * a1;
+                const float r1 = p[64] * a0 + p[65] * a1;
+                v = r0 * b0 + r1 * b1;
+            }
+            A.out[((int64_t)blockIdx.z * A.lh + Y) * A.lw + X] = v;
+        }
+    }
+}
+
 // ---- polynomial expansion (FarnebackPolyExp, n = 5) ------------------------------------------------
 // Tile of PE_TY rows x PE_TX columns per workgroup: the vertical pass (float) fills LDS for the tile's
 // columns plus a 5-column replicated halo, the horizontal pass (double accumulators) reads it back.
@@ -604,6 +746,38 @@ void launch_fb_blur(hipStream_t st, const uint8_t *gray, int pitch, int64_t plan
                        plane_stride, h, w, T, cols, nc, tmp);
     hipLaunchKernelGGL(k_fb_blur_v, dim3((nc + 255) / 256, (nr + FB_RB - 1) / FB_RB, planes), dim3(256), 0, st, tmp, h, w, T, cols,
                        nc, rows, nr, out);
+}
+
+// The level image of every plane in one launch (see k_fb_level).  T == nullptr: the finest level (lh x lw = h x w, no
+// resize).  Returns false when the level's patch does not fit the LDS budget (caller falls back to the three-kernel path).
+bool launch_fb_level(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int planes, int h, int w,
+                     const fb_taps &K, const fb_resize_tabs *T, float *out, int lh, int lw)
+{
+    const int r = K.ksize >> 1;
+    fb_level_args A;
+    A.gray = gray; A.pitch = pitch; A.plane_stride = plane_stride; A.h = h; A.w = w;
+    A.out = out; A.lh = lh; A.lw = lw;
+    A.sx = A.sy = nullptr; A.xa = A.yb = nullptr; A.mode = 0;
+    if (!T) {
+        A.cap_x = 64 + 2 * r; A.cap_y = 64 + 2 * r;
+        const size_t lds = fb_level_lds(A.cap_x, A.cap_y, 64);
+        if (lds > 64 * 1024) return false;
+        hipLaunchKernelGGL((k_fb_level<1, 64>), dim3((lw + 63) / 64, (lh + 63) / 64, planes), dim3(256), lds, st, A, K);
+        return true;
+    }
+    if (!T->sx || !T->sy) return false;
+    A.sx = T->sx; A.sy = T->sy; A.xa = T->xa; A.yb = T->yb; A.mode = T->mode;
+    A.cap_x = T->span_x32 + 2 * r;
+    // few taps: tall tiles (32 level rows); many taps (coarse levels): 8 level rows, the patch is 2r rows taller than the tile
+    const bool tall = r <= 2;
+    A.cap_y = (tall ? T->span_y32 : T->span_y8) + 2 * r;
+    const size_t lds = fb_level_lds(A.cap_x, A.cap_y, tall ? 64 : 16);
+    if (lds > 64 * 1024) return false;
+    if (tall)
+        hipLaunchKernelGGL((k_fb_level<2, 64>), dim3((lw + 31) / 32, (lh + 31) / 32, planes), dim3(256), lds, st, A, K);
+    else
+        hipLaunchKernelGGL((k_fb_level<2, 16>), dim3((lw + 31) / 32, (lh + 7) / 8, planes), dim3(256), lds, st, A, K);
+    return true;
 }
 
 void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, float *dst, int dh, int dw, int images,

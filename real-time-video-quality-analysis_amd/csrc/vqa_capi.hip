@@ -357,6 +357,39 @@ static int get_fb_tabs(vqa_ctx *c, int sh, int sw, int dh, int dw, fb_resize_tab
     HIPCHK(c, hipMemcpy(t.xa, xa.data(), sizeof(float) * 2 * dw, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(t.yofs, yo.data(), sizeof(int32_t) * dh, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(t.yb, yb.data(), sizeof(float) * 2 * dh, hipMemcpyHostToDevice));
+    if (dw <= sw && dh <= sh) {
+        // the samples of each level column / row as the fused level kernel wants them, and their extent per tile
+        std::vector<int32_t> sx(2 * (size_t)dw), sy(2 * (size_t)dh);
+        for (int d = 0; d < dw; d++) {
+            sx[2 * d] = t.mode == 1 ? 2 * d : xo[d];
+            sx[2 * d + 1] = t.mode == 1 ? 2 * d + 1 : (xo[d] + 1 < sw ? xo[d] + 1 : sw - 1);
+        }
+        for (int d = 0; d < dh; d++) {
+            const int y0 = yo[d] < 0 ? 0 : (yo[d] > sh - 1 ? sh - 1 : yo[d]);
+            const int y1 = yo[d] + 1 < 0 ? 0 : (yo[d] + 1 > sh - 1 ? sh - 1 : yo[d] + 1);
+            sy[2 * d] = t.mode == 1 ? 2 * d : y0;
+            sy[2 * d + 1] = t.mode == 1 ? 2 * d + 1 : y1;
+        }
+        auto span = [](const std::vector<int32_t> &v, int n, int tile) {
+            int m = 0;
+            bool mono = true;
+            for (size_t i = 1; i < v.size(); i++) mono = mono && v[i] >= v[i - 1];
+            if (!mono) return -1;
+            for (int a = 0; a < n; a += tile) {
+                const int b = (a + tile < n ? a + tile : n) - 1;
+                const int e = v[2 * b + 1] - v[2 * a] + 1;
+                m = e > m ? e : m;
+            }
+            return m;
+        };
+        t.span_x32 = span(sx, dw, 32); t.span_y8 = span(sy, dh, 8); t.span_y32 = span(sy, dh, 32);
+        if (t.span_x32 > 0 && t.span_y8 > 0 && t.span_y32 > 0) {
+            HIPCHK(c, hipMalloc((void **)&t.sx, sizeof(int32_t) * sx.size()));
+            HIPCHK(c, hipMalloc((void **)&t.sy, sizeof(int32_t) * sy.size()));
+            HIPCHK(c, hipMemcpy(t.sx, sx.data(), sizeof(int32_t) * sx.size(), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(t.sy, sy.data(), sizeof(int32_t) * sy.size(), hipMemcpyHostToDevice));
+        }
+    }
     if (t.mode == 0 && (dw < sw || dh < sh)) {
         // what the bilinear taps read: columns xofs, min(xofs + 1, sw - 1); rows clamp(yofs), clamp(yofs + 1)
         std::vector<int32_t> cs, rs;
@@ -405,6 +438,13 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
 #else
     const bool two_kernel = false;
 #endif
+    // the level image: one fused kernel (blur + resize); the three-kernel form is the fallback for levels whose patch
+    // exceeds the LDS budget (and VQA_FB_LEVEL_VARIANT=1 in the lab build)
+#ifdef VQA_AB_VARIANTS
+    const bool three_kernel = ab_knob("VQA_FB_LEVEL_VARIANT", 0) == 1;
+#else
+    const bool three_kernel = false;
+#endif
     int mc = (int)((12ull << 30) / ((two_kernel ? 72 : 52) * P));
     mc = mc < 1 ? 1 : (mc > n ? n : mc);
     int rc;
@@ -440,17 +480,18 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
             // exact 2x decimation cannot occur here (this is an upscale), so the bilinear tables always apply
             if (!coarsest && (rc = get_fb_tabs(c, ph, pw, lh, lw, TF))) return rc;
             // every plane once: blur (only where the resize will sample), resize to the level, polynomial expansion
-            const float *level_img = blur;
+            const float *level_img = img;
+            const fb_taps K = fb_gauss_taps(smooth_sz, sigma);
             if (lw != w || lh != h) {
                 fb_resize_tabs T;
                 if ((rc = get_fb_tabs(c, h, w, lh, lw, T))) return rc;
-                launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, fb_gauss_taps(smooth_sz, sigma), T.cols, T.nc, T.rows,
-                               T.nr, tmp, blur);
-                launch_fb_resize(st, blur, h, w, 1, img, lh, lw, planes, T, 1.f, false);
-                level_img = img;
-            } else {
-                launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, fb_gauss_taps(smooth_sz, sigma), nullptr, 0, nullptr, 0,
-                               tmp, blur);
+                if (three_kernel || !launch_fb_level(st, g0, gp, plane_stride, planes, h, w, K, &T, img, lh, lw)) {
+                    launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, K, T.cols, T.nc, T.rows, T.nr, tmp, blur);
+                    launch_fb_resize(st, blur, h, w, 1, img, lh, lw, planes, T, 1.f, false);
+                }
+            } else if (three_kernel || !launch_fb_level(st, g0, gp, plane_stride, planes, h, w, K, nullptr, img, lh, lw)) {
+                launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, K, nullptr, 0, nullptr, 0, tmp, blur);
+                level_img = blur;
             }
             launch_fb_polyexp(st, level_img, planes, lh, lw, PC, R);
 #ifdef VQA_AB_VARIANTS
@@ -599,6 +640,8 @@ int vqa_destroy(vqa_ctx *c)
         (void)hipFree(kv.second.xofs); (void)hipFree(kv.second.xa); (void)hipFree(kv.second.yofs); (void)hipFree(kv.second.yb);
         if (kv.second.cols) (void)hipFree(kv.second.cols);
         if (kv.second.rows) (void)hipFree(kv.second.rows);
+        if (kv.second.sx) (void)hipFree(kv.second.sx);
+        if (kv.second.sy) (void)hipFree(kv.second.sy);
     }
     for (auto &kv : c->dct_mats) (void)hipFree(kv.second);
     for (auto &kv : c->fft_plans) { (void)hipFree((void *)kv.second.tw); (void)hipFree((void *)kv.second.post); }

@@ -119,10 +119,18 @@ struct fb_resize_tabs { // cv2.resize INTER_LINEAR tables for float data (device
     // the source columns / rows a bilinear downscale actually samples (sorted, unique); null = all of them
     int32_t *cols = nullptr, *rows = nullptr;
     int nc = 0, nr = 0;
+    // the fused level kernel's view of a downscale: the two source columns / rows each level column / row samples
+    // (clamps applied; 2 * dsize entries) and the widest extent of them over tiles of 32 columns, 8 and 32 rows
+    int32_t *sx = nullptr, *sy = nullptr;
+    int span_x32 = 0, span_y8 = 0, span_y32 = 0;
 };
 // blurred values are produced only at the columns / rows listed (all when null): the level's resize reads nothing else
 void launch_fb_blur(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int planes, int h, int w,
                     const fb_taps &T, const int32_t *cols, int nc, const int32_t *rows, int nr, float *tmp, float *out);
+// Gaussian blur of the u8 planes + resize to the level in one kernel; T = nullptr: finest level (no resize).  false: the
+// level does not fit its LDS budget - use launch_fb_blur (+ launch_fb_resize)
+bool launch_fb_level(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int planes, int h, int w,
+                     const fb_taps &K, const fb_resize_tabs *T, float *out, int lh, int lw);
 void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, float *dst, int dh, int dw, int images,
                       const fb_resize_tabs &T, float mul, bool apply_mul);
 void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out);
