@@ -400,7 +400,7 @@ __device__ __forceinline__ void fb_flow_at(const float *__restrict__ flow /* the
     dx = 0.f;
     dy = 0.f;
     if (SRC == 0) {
-        const float2 f = *reinterpret_cast<const float2 *>(flow + ((int64_t)y * w + x) * 2);
+        const float2 f = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(flow) + (uint32_t)(y * w + x) * 8u);
         dx = f.x;
         dy = f.y;
     } else if (SRC == 1) {
@@ -423,23 +423,30 @@ __device__ __forceinline__ void fb_flow_at(const float *__restrict__ flow /* the
 // five coefficient planes of P = h * w floats each
 struct __attribute__((packed, aligned(4))) fb_f2 { float a, b; }; // two adjacent floats, 4-byte aligned: one global_load_dwordx2
 
+// Loads at (uniform base) + (32-bit byte offset): the base stays in scalar registers and the lane's offset is ONE
+// register (global_load ... v_off, s[base]); with 64-bit per-lane pointers the march spent 18 vector instructions per
+// row on address arithmetic.  Offsets fit: h * w <= 2^28 pixels (include/vqa.h), 8 bytes per pixel at most.
+__device__ __forceinline__ float fb_ld(const float *base, uint32_t off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off); }
+__device__ __forceinline__ fb_f2 fb_ld2(const float *base, uint32_t off) { return *reinterpret_cast<const fb_f2 *>(reinterpret_cast<const char *>(base) + off); }
+
 __device__ __forceinline__ void fb_products(const float *__restrict__ R0, const float *__restrict__ R1, int h, int w, int x,
                                             int y, float dx, float dy, float m[5])
 {
     const int64_t P = (int64_t)h * w;
-    const float *r0 = R0 + (int64_t)y * w + x;
-    const float r00 = r0[0], r01 = r0[P], r02 = r0[2 * P], r03 = r0[3 * P], r04 = r0[4 * P];
+    const uint32_t o0 = (uint32_t)(y * w + x) * 4u;
+    const float r00 = fb_ld(R0, o0), r01 = fb_ld(R0 + P, o0), r02 = fb_ld(R0 + 2 * P, o0), r03 = fb_ld(R0 + 3 * P, o0),
+                r04 = fb_ld(R0 + 4 * P, o0);
     float fx = x + dx, fy = y + dy;
     const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     float r2, r3, r4, r5, r6;
     fx -= x1; fy -= y1;
     if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        const float *p = R1 + (int64_t)y1 * w + x1;
+        const uint32_t o1 = (uint32_t)(y1 * w + x1) * 4u, o2 = o1 + (uint32_t)w * 4u;
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
         float v[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            const fb_f2 t = *reinterpret_cast<const fb_f2 *>(p + c * P), b = *reinterpret_cast<const fb_f2 *>(p + c * P + w);
+            const fb_f2 t = fb_ld2(R1 + c * P, o1), b = fb_ld2(R1 + c * P, o2);
             v[c] = a00 * t.a + a01 * t.b + a10 * b.a + a11 * b.b;
         }
         r2 = v[0]; r3 = v[1];
@@ -583,18 +590,28 @@ __global__ __launch_bounds__(BS_NT) void k_fb_blur_solve(const float *__restrict
 //     the same float difference, in the same order, as optflowgf.cpp / oracle fb_blur_solve; with one strip per frame
 //     (ns = 1) the column sums are the oracle's bit for bit, drift of the float differences included; a lower strip
 //     starts from the plain sum of its first 15 rows;
-//   * two rows of column sums go through LDS per step; lane pair (2j, 2j+1) takes the output columns 2j, 2j+1 of one
-//     row each: 16 doubles -> the 15-column window sum of the first and, sliding by one, of the second (8 ds_read_b128
-//     per channel for two outputs); then the regularised 2x2 solve and the flow store.
-// The horizontal window is summed left to right per output, not slid along the whole row as OpenCV does: that
+//   * FI_R rows of column sums go through LDS per step; a group of FI_R lanes takes FI_R adjacent output columns of one
+//     row each: FI_R + 14 doubles -> the 15-column window sum of the first and, sliding by one column at a time, of
+//     the others ((FI_R + 14) / FI_R LDS reads and (14 + 2 (FI_R - 1)) / FI_R additions per output and channel: 4.5 and
+//     5 for FI_R = 4, 8 and 8.5 for 2); then the regularised 2x2 solve and the flow store.
+// The horizontal window is summed left to right per group, not slid along the whole row as OpenCV does: that
 // differs at the 1e-16 level only.  Products are never written: per pixel the iteration reads 20 B (R0) + 20 B (R1,
 // gathered) + 8 B (flow) and writes 8 B.
 // grid = (ncb * ns, pairs), block = FI_NT; QS = rows per strip, a multiple of 16 (static ring slots)
 constexpr int FI_NT = 256, FI_OUT = FI_NT - 14;
 #ifndef FB_PROBE
-#define FB_PROBE 0 // measurement builds only (scripts/build_probes.sh FB_PROBE 1 2): 1 = no horizontal phase, 2 = no products
+#define FB_PROBE 0 // measurement builds only (scripts/build_probes.sh FB_PROBE 2): 2 = no products (constant instead)
 #endif
-constexpr int FI_LD = 272; // doubles per LDS row: 2176 B = 8 * 256 + 128, so the two rows of a lane pair sit 32 banks apart
+#ifndef FI_ROWS
+#define FI_ROWS 2  // rows per LDS round trip (2 = shipped; 4 = measurement build: 222 VGPRs, two waves per SIMD, 1.5x slower)
+#endif
+constexpr int FI_R = FI_ROWS;
+// LDS: vs[channel][row of the step][column] in doubles.  The lanes of a group read the SAME columns of different rows
+// with ds_read_b128, so the rows of a step are staggered by 16-byte slots that the groups' own 32-byte spacing leaves
+// free: row offsets 0, 16, 128, 144 bytes modulo 256.
+constexpr int FI_ROWB = 2304;                               // bytes per row: 9 * 256 >= (256 + 3 + 2) * 8
+constexpr int FI_CHB = FI_R * FI_ROWB + 256;                // bytes per channel
+__device__ __forceinline__ constexpr int fi_row_off(int q) { return q * FI_ROWB + (q & 1) * 16 + (q >> 1) * 128; }
 
 template <int SRC>
 __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, const float *__restrict__ fin, int h, int w,
@@ -603,7 +620,10 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
                                                    const int32_t *__restrict__ yofs, const float *__restrict__ yb, float mul,
                                                    int ncb, int QS)
 {
-    __shared__ double vs[5][2][FI_LD];
+    static_assert(FI_R == 2 || FI_R == 4, "rows per step = lanes per group = adjacent output columns per lane");
+    // two buffers, alternating by step: ONE barrier per step (a step's stores go to the buffer read two steps ago, and every
+    // thread passed the barrier in between only after finishing those reads; 16 / FI_R steps per loop iteration is even)
+    __shared__ __align__(16) unsigned char vsb[2][5 * FI_CHB];
     const int t = threadIdx.x;
     const int cb = blockIdx.x % ncb, sb = blockIdx.x / ncb;
     const int x0 = cb * FI_OUT, ys = sb * QS;
@@ -619,38 +639,43 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
 #pragma unroll
         for (int c = 0; c < 5; c++) ring[s][c] = 0.f;
     double vsum[5] = {0., 0., 0., 0., 0.};
-    // horizontal role: output columns k0, k0 + 1 (relative to x0) of row (t & 1) of the step
-    const int k0 = t & ~1, hrow = t & 1;
-    const double *vrow = &vs[0][hrow][k0];
-    const bool out0 = k0 < FI_OUT && x0 + k0 < w, out1 = k0 + 1 < FI_OUT && x0 + k0 + 1 < w;
+    // horizontal role: output columns k0 .. k0 + FI_R - 1 (relative to x0) of row (t % FI_R) of the step
+    const int k0 = t & ~(FI_R - 1), hrow = t & (FI_R - 1);
+    const int vrow = (hrow * FI_ROWB + (hrow & 1) * 16 + (hrow >> 1) * 128) + k0 * 8;
+    bool outk[FI_R];
+#pragma unroll
+    for (int j = 0; j < FI_R; j++) outk[j] = k0 + j < FI_OUT && x0 + k0 + j < w;
 
     // Row gi of the strip's march: output row y = ys - 16 + gi, entering product row rho = y + 7 (clamped = replicated).
-    // gi = 0 is a dummy (keeps steps of two rows aligned with the 16-slot ring), gi = 1..15 prime the column sums with
+    // gi = 0 is a dummy (keeps the steps aligned with the 16-slot ring), gi = 1..15 prime the column sums with
     // the rows ys-8 .. ys+6 (the ring is zero there, so the difference form adds the plain values), gi >= 16 emit.
-    // The displacement of a step's two rows is fetched one step ahead: the gathers of R1 depend on it, and the two
+    // The displacement of a step's rows is fetched one step ahead: the gathers of R1 depend on it, and the two
     // dependent round trips per step were the kernel's critical path.
     auto row_of = [&](int y) { return min(max(y + BS_M, 0), h - 1); };
-    float dxn[2], dyn[2];
+    float dxn[FI_R], dyn[FI_R];
 #pragma unroll
-    for (int q = 0; q < 2; q++) fb_flow_at<SRC>(fp, w, xx, row_of(ys - 16 + q), ch, cw, xofs, xa, yofs, yb, mul, dxn[q], dyn[q]);
+    for (int q = 0; q < FI_R; q++) fb_flow_at<SRC>(fp, w, xx, row_of(ys - 16 + q), ch, cw, xofs, xa, yofs, yb, mul, dxn[q], dyn[q]);
     for (int base = 0;; base += 16) {
         const int yb0 = ys - 16 + base;
         if (yb0 >= yend) break;
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const float dx0 = dxn[0], dy0 = dyn[0], dx1 = dxn[1], dy1 = dyn[1];
-            float cur[2][5];
+        for (int i = 0; i < 16; i += FI_R) {
+            float dxc[FI_R], dyc[FI_R], cur[FI_R][5];
+#pragma unroll
+            for (int q = 0; q < FI_R; q++) { dxc[q] = dxn[q]; dyc[q] = dyn[q]; }
+#pragma unroll
+            for (int q = 0; q < FI_R; q++) {
 #if FB_PROBE == 2
-            for (int c = 0; c < 5; c++) { cur[0][c] = dx0 + c; cur[1][c] = dy1 + dx1 + dy0 - c; }
+                for (int c = 0; c < 5; c++) cur[q][c] = dxc[q] + dyc[q] * c;
 #else
-            fb_products(R0, R1, h, w, xx, row_of(yb0 + i), dx0, dy0, cur[0]);
-            fb_products(R0, R1, h, w, xx, row_of(yb0 + i + 1), dx1, dy1, cur[1]);
+                fb_products(R0, R1, h, w, xx, row_of(yb0 + i + q), dxc[q], dyc[q], cur[q]);
 #endif
+            }
 #pragma unroll
-            for (int q = 0; q < 2; q++)
-                fb_flow_at<SRC>(fp, w, xx, row_of(yb0 + i + 2 + q), ch, cw, xofs, xa, yofs, yb, mul, dxn[q], dyn[q]);
+            for (int q = 0; q < FI_R; q++)
+                fb_flow_at<SRC>(fp, w, xx, row_of(yb0 + i + FI_R + q), ch, cw, xofs, xa, yofs, yb, mul, dxn[q], dyn[q]);
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
+            for (int q = 0; q < FI_R; q++) {
                 const int y = yb0 + i + q, rho = y + BS_M;
                 const bool dummy = i + q == 0 && base == 0;
 #pragma unroll
@@ -661,51 +686,44 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
                     if (dummy) add = 0.f;
                     vsum[c] += (double)add;
                     ring[(i + q + 7) & 15][c] = dummy ? 0.f : cur[q][c];
-                    vs[c][q][t] = vsum[c];
+                    *reinterpret_cast<double *>(vsb[(i / FI_R) & 1] + c * FI_CHB + fi_row_off(q) + t * 8) = vsum[c];
                 }
             }
             if (base > 0) {
                 __syncthreads();
                 const int yo = yb0 + i + hrow;
-#if FB_PROBE == 1
-                if (yo < yend && out0) {
-                    float *f = fo + ((int64_t)yo * w + x0 + k0) * 2;
-                    f[0] = (float)vrow[0]; f[1] = (float)vrow[FI_LD]; f[2] = (float)vrow[1]; f[3] = (float)vrow[FI_LD + 1];
-                }
-#else
-                if (yo < yend && out0) {
-                    double s0[5], s1[5];
+                if (yo < yend && outk[0]) {
+                    double sw[FI_R][5];
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
-                        const double2 *p = reinterpret_cast<const double2 *>(vrow + (size_t)c * 2 * FI_LD);
-                        double2 v[8];
+                        const double2 *p = reinterpret_cast<const double2 *>(vsb[(i / FI_R) & 1] + vrow + c * FI_CHB);
+                        constexpr int NV = (FI_R + 14 + 1) / 2;
+                        double2 v[NV];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) v[k] = p[k];
-                        double a = v[0].x;
-                        a += v[0].y;
+                        for (int k = 0; k < NV; k++) v[k] = p[k];
+                        auto at = [&](int k) { return (k & 1) ? v[k >> 1].y : v[k >> 1].x; };
+                        double a = at(0);
 #pragma unroll
-                        for (int k = 1; k < 7; k++) { a += v[k].x; a += v[k].y; }
-                        a += v[7].x;
-                        s0[c] = a;
-                        s1[c] = a + (v[7].y - v[0].x);
+                        for (int k = 1; k < 15; k++) a += at(k);
+                        sw[0][c] = a;
+#pragma unroll
+                        for (int j = 1; j < FI_R; j++) {
+                            a = a + (at(14 + j) - at(j - 1));
+                            sw[j][c] = a;
+                        }
                     }
                     const double scale = 1. / 225.;
                     float *f = fo + ((int64_t)yo * w + x0 + k0) * 2;
-                    {
-                        const double g11 = s0[0] * scale, g12 = s0[1] * scale, g22 = s0[2] * scale, h1 = s0[3] * scale, h2 = s0[4] * scale;
+#pragma unroll
+                    for (int j = 0; j < FI_R; j++) {
+                        if (!outk[j]) continue;
+                        const double g11 = sw[j][0] * scale, g12 = sw[j][1] * scale, g22 = sw[j][2] * scale, h1 = sw[j][3] * scale,
+                                     h2 = sw[j][4] * scale;
                         const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                        f[0] = (float)((g11 * h2 - g12 * h1) * idet);
-                        f[1] = (float)((g22 * h1 - g12 * h2) * idet);
-                    }
-                    if (out1) {
-                        const double g11 = s1[0] * scale, g12 = s1[1] * scale, g22 = s1[2] * scale, h1 = s1[3] * scale, h2 = s1[4] * scale;
-                        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                        f[2] = (float)((g11 * h2 - g12 * h1) * idet);
-                        f[3] = (float)((g22 * h1 - g12 * h2) * idet);
+                        f[2 * j] = (float)((g11 * h2 - g12 * h1) * idet);
+                        f[2 * j + 1] = (float)((g22 * h1 - g12 * h2) * idet);
                     }
                 }
-#endif
-                __syncthreads();
             }
         }
     }
@@ -825,26 +843,29 @@ void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int 
 
 #endif
 
-// One fused iteration: flow_out = solve(box15x15(products(R, flow_in))).  flow_in: coarse != nullptr -> the coarser
-// level's ch x cw field, upsampled and scaled by mul in flight (first iteration of a level); else `flow` (same size);
-// both null -> zero flow (coarsest level).  flow_out must not alias the input: neighbours read it while it is written.
-void launch_fb_iter(hipStream_t st, const float *R, const float *flow, const float *coarse, int ch, int cw,
-                    const fb_resize_tabs &T, float mul, int pairs, int h, int w, float *flow_out)
+// One fused iteration: flow_out = solve(box15x15(products(R, flow))).  flow == nullptr: zero flow (coarsest level).
+// flow_out must not alias the input: neighbours read it while it is written.  (The kernel can also upsample a coarser
+// field in flight - SRC = 1 - but that put eight dependent loads per row on the march's critical path and cost more than
+// writing the upsampled field once with k_fb_resize<2>; not instantiated.)
+void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *flow_out)
 {
     const int ncb = (w + FI_OUT - 1) / FI_OUT;
-    // strips: one per frame when that fills the chip (the column sums then follow OpenCV's whole-frame order exactly),
-    // more (>= 32 rows each: a strip re-forms 15 rows of products to prime its sums) when a launch would otherwise have
-    // fewer than ~3 workgroups per CU - a workgroup's march is a chain of dependent steps, ~3 us per two rows
-    int ns = (int)((768 + (long long)ncb * pairs - 1) / ((long long)ncb * pairs));
-    const int cap = h / 32 < 1 ? 1 : h / 32;
-    ns = ns < 1 ? 1 : (ns > cap ? cap : ns);
-    const int QS = ((h + ns - 1) / ns + 15) / 16 * 16;
-    ns = (h + QS - 1) / QS;
+    // Strips.  A workgroup's march is a chain of dependent steps, so a launch costs (residency rounds) x (rows a workgroup
+    // marches): the chip holds 768 of these workgroups at once (3 per CU: 160 VGPRs, 48 KB LDS).  Take the strip count
+    // that minimises rounds x (strip rows + 16 priming rows); strips are >= 32 rows.  One strip per frame - when that
+    // wins - makes the column sums follow OpenCV's whole-frame order exactly.
+    int ns = 1, QS = (h + 15) / 16 * 16;
+    {
+        const int cap = h / 32 < 1 ? 1 : (h / 32 > 64 ? 64 : h / 32);
+        long long best = -1;
+        for (int n = 1; n <= cap; n++) {
+            const int qs = ((h + n - 1) / n + 15) / 16 * 16, ne = (h + qs - 1) / qs;
+            const long long blocks = (long long)ncb * ne * pairs, cost = ((blocks + 767) / 768) * (qs + 16);
+            if (best < 0 || cost < best) { best = cost; ns = ne; QS = qs; }
+        }
+    }
     dim3 grid(ncb * ns, pairs);
-    if (coarse)
-        hipLaunchKernelGGL(k_fb_iter<1>, grid, dim3(FI_NT), 0, st, R, coarse, h, w, flow_out, ch, cw, T.xofs, T.xa, T.yofs, T.yb,
-                           mul, ncb, QS);
-    else if (flow)
+    if (flow)
         hipLaunchKernelGGL(k_fb_iter<0>, grid, dim3(FI_NT), 0, st, R, flow, h, w, flow_out, 0, 0, nullptr, nullptr, nullptr,
                            nullptr, 0.f, ncb, QS);
     else

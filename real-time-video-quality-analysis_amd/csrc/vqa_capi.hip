@@ -516,7 +516,7 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
                     in = prev_flow;
                 }
                 for (int i = 0; i < iters; i++) {
-                    launch_fb_iter(st, R, in, nullptr, 0, 0, TF, 0.f, pairs, lh, lw, flow);
+                    launch_fb_iter(st, R, in, pairs, lh, lw, flow);
                     float *t = flow; flow = prev_flow; prev_flow = t;
                     in = prev_flow;
                 }

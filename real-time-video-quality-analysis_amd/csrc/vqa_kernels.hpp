@@ -134,10 +134,9 @@ bool launch_fb_level(hipStream_t st, const uint8_t *gray, int pitch, int64_t pla
 void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, float *dst, int dh, int dw, int images,
                       const fb_resize_tabs &T, float mul, bool apply_mul);
 void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out);
-// one flow iteration (products + 15x15 box sums + solve, fused; the products never reach HBM).  Input flow: `coarse`
-// (ch x cw, upsampled and scaled in flight) or `flow` (same size) or neither (zero); flow_out must not alias it
-void launch_fb_iter(hipStream_t st, const float *R, const float *flow, const float *coarse, int ch, int cw,
-                    const fb_resize_tabs &T, float mul, int pairs, int h, int w, float *flow_out);
+// one flow iteration (products + 15x15 box sums + solve, fused; the products never reach HBM).  flow == nullptr: zero
+// flow (coarsest level); flow_out must not alias the input
+void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *flow_out);
 #ifdef VQA_AB_VARIANTS // the two-kernel form of rounds 2-3 (VQA_FB_VARIANT=1 in the lab build)
 void launch_fb_update(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *M);
 void launch_fb_update_first(hipStream_t st, const float *R, const float *coarse, int ch, int cw, const fb_resize_tabs &T,
