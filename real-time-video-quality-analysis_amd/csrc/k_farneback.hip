@@ -326,10 +326,10 @@ __global__ __launch_bounds__(256) void k_fb_level(fb_level_args A, fb_taps T)
 // ---- polynomial expansion (FarnebackPolyExp, n = 5) ------------------------------------------------
 // Tile of PE_TY rows x PE_TX columns per workgroup: the vertical pass (float) fills LDS for the tile's
 // columns plus a 5-column replicated halo, the horizontal pass (double accumulators) reads it back.
-constexpr int PE_TX = 64, PE_TY = 4, PE_N = 5;
-constexpr int PE_TILES = 8; // consecutive row tiles per workgroup (fewer, longer workgroups: see FB_RB)
+constexpr int PE_TX = 64, PE_TY = 16, PE_N = 5;   // 16 rows per tile: the vertical pass re-reads 26 rows per 16 (4-row tiles: 14 per 4)
+constexpr int PE_TILES = 2; // consecutive row tiles per workgroup
 
-// grid = (ceil(w/PE_TX), ceil(h/(PE_TY * PE_TILES)), planes), block = 256 (thread = one output pixel per tile)
+// grid = (ceil(w/PE_TX), ceil(h/(PE_TY * PE_TILES)), planes), block = 256
 __global__ __launch_bounds__(256) void k_fb_polyexp(const float *__restrict__ in, int h, int w, fb_poly C,
                                                     float *__restrict__ out)
 {
@@ -361,29 +361,33 @@ __global__ __launch_bounds__(256) void k_fb_polyexp(const float *__restrict__ in
             row[ty][tx][0] = t0; row[ty][tx][1] = t1; row[ty][tx][2] = t2;
         }
         __syncthreads();
-        const int ty = threadIdx.x / PE_TX, tx = threadIdx.x % PE_TX;
-        const int x = x0 + tx, y = y0 + ty;
-        if (x >= w || y >= h) continue;
-        const float(*r)[3] = &row[ty][tx + PE_N];
-        double b1 = r[0][0] * g[0], b2 = 0, b3 = r[0][1] * g[0], b4 = 0, b5 = r[0][2] * g[0], b6 = 0;
+        const int tx = threadIdx.x % PE_TX, x = x0 + tx;
+        if (x >= w) continue;
+#pragma unroll 2
+        for (int ty = threadIdx.x / PE_TX; ty < PE_TY; ty += 256 / PE_TX) {
+            const int y = y0 + ty;
+            if (y >= h) break;
+            const float(*r)[3] = &row[ty][tx + PE_N];
+            double b1 = r[0][0] * g[0], b2 = 0, b3 = r[0][1] * g[0], b4 = 0, b5 = r[0][2] * g[0], b6 = 0;
 #pragma unroll
-        for (int k = 1; k <= PE_N; k++) {
-            const double tg = r[k][0] + r[-k][0];
-            b1 += tg * g[k];
-            b4 += tg * xxg[k];
-            b2 += (r[k][0] - r[-k][0]) * xg[k];
-            b3 += (r[k][1] + r[-k][1]) * g[k];
-            b6 += (r[k][1] - r[-k][1]) * xg[k];
-            b5 += (r[k][2] + r[-k][2]) * g[k];
+            for (int k = 1; k <= PE_N; k++) {
+                const double tg = r[k][0] + r[-k][0];
+                b1 += tg * g[k];
+                b4 += tg * xxg[k];
+                b2 += (r[k][0] - r[-k][0]) * xg[k];
+                b3 += (r[k][1] + r[-k][1]) * g[k];
+                b6 += (r[k][1] - r[-k][1]) * xg[k];
+                b5 += (r[k][2] + r[-k][2]) * g[k];
+            }
+            // the five coefficients go to five PLANES (channel-major): the flow iteration reads them one column per lane,
+            // and planar the loads of a row are contiguous and the bilinear corners x1, x1 + 1 are one 8-byte load
+            float *d = out + (int64_t)blockIdx.z * P * 5 + (int64_t)y * w + x;
+            d[P] = (float)(b2 * C.ig11);
+            d[0] = (float)(b3 * C.ig11);
+            d[3 * P] = (float)(b1 * C.ig03 + b4 * C.ig33);
+            d[2 * P] = (float)(b1 * C.ig03 + b5 * C.ig33);
+            d[4 * P] = (float)(b6 * C.ig55);
         }
-        // the five coefficients go to five PLANES (channel-major): the flow iteration reads them one column per lane, and
-        // planar the loads of a row are contiguous and the bilinear corners x1, x1 + 1 are one 8-byte load
-        float *d = out + (int64_t)blockIdx.z * P * 5 + (int64_t)y * w + x;
-        d[P] = (float)(b2 * C.ig11);
-        d[0] = (float)(b3 * C.ig11);
-        d[3 * P] = (float)(b1 * C.ig03 + b4 * C.ig33);
-        d[2 * P] = (float)(b1 * C.ig03 + b5 * C.ig33);
-        d[4 * P] = (float)(b6 * C.ig55);
     }
 }
 

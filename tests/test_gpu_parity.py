@@ -767,13 +767,17 @@ _VARIANT_CODE = (
     "    sse, ssim = pl.frame_quality(fr[0], fr[1], bgr_planes(h, w), 'gauss')\n"
     "    for p in range(3):\n"
     "        assert int(q[0, p]['sse']) == sse[p] and abs(q[0, p]['ssim'] - ssim[p]) <= 1e-4 * abs(ssim[p]), ('ssim', kind, p)\n"
+    "    fb = eng.complexity(fr[1:3], prev0=fr[0], mask=N.M_MOTION, motion_mode=N.MOTION_FARNEBACK)\n"
+    "    for i in range(2):\n"
+    "        want = co.farneback(co.bgr2gray(fr[i]), co.bgr2gray(fr[i + 1]))\n"
+    "        assert abs(float(fb[i]['flow_mag_mean']) - want) <= 1e-4 * want + 1e-7, ('farneback', kind, i)\n"
     "print('VARIANT-OK')\n"
 )
 
 
 @pytest.mark.parametrize("knob", ["VQA_DCT_VARIANT=4", "VQA_DCT_VARIANT=3", "VQA_DCT_VARIANT=1", "VQA_DCT_LOAD_EARLY=1", "VQA_DCT_FCH=3",
                                   "VQA_SSIM_VARIANT=1", "VQA_SSIM_VARIANT=4", "VQA_NMS_VARIANT=1", "VQA_NMS_VARIANT=2", "VQA_HYST_SUB=1",
-                                  "VQA_HYST_SUB=5", "VQA_HYST_WIDE=1", "NONE=0"])
+                                  "VQA_HYST_SUB=5", "VQA_HYST_WIDE=1", "VQA_FB_VARIANT=1", "VQA_FB_LEVEL_VARIANT=1", "NONE=0"])
 def test_ab_knob_variants_keep_parity(knob):
     """LAB build (csrc/lab/libvqa_hip_lab.so, loaded through VQA_LIB_PATH): every superseded kernel variant kept for
     re-measurement (LAB_NOTES.md) still matches the oracle (selectors are read once per process => one subprocess per
