@@ -14,13 +14,15 @@
 //
 //   k_dct_fft_rows: one workgroup transforms rows: u8 samples -> LDS (centred at 128: the constant's DC term is put
 //                   back analytically, which keeps the FFT's rounding noise relative to the texture, not to the
-//                   offset) -> Stockham autosort passes of radix 8 / 4 / 2 / 3 / 5 in LDS -> two float planes.
+//                   offset) -> Stockham autosort passes of radix 8 / 4 / 2 / 3 / 5 in LDS, IN PLACE (registers hold a
+//                   pass between its reads and its writes: half the LDS, 8 workgroups per CU) -> two float planes.
 //   k_dct_fft_cols: one workgroup transforms a pair of adjacent columns of both planes the same way and reduces
 //                   sum Ya^2 and sum |Yb| on the fly: the 2-D coefficients are never written.
 // Lengths must be even and factor into 2, 3, 5 (1080p, 2160p, 720p, 480p ... do); other sizes take k_dct_full.hip.
 // No dense contraction is left, so nothing here uses MFMA.  Roofline: HBM (P bytes in + 8P out, 8P in per frame);
-// measured at 1080p, 64 frames: rows 1.10 ms + columns 1.96 ms against 15.1 ms for the matrix-core version - both passes are
-// bound by the barriers between their short radix passes (latency / occupancy), not by HBM.
+// measured at 1080p, 64 frames: rows 0.79 ms + columns 1.5 ms against 15.1 ms for the matrix-core version (first FFT
+// version: 1.10 + 1.96) - the row pass is bound by the barriers between its short radix passes (latency / occupancy),
+// the column pass by its strided reads, neither by HBM.
 #include "vqa_dev.hpp"
 #include "vqa_kernels.hpp"
 
@@ -88,8 +90,69 @@ __device__ __forceinline__ void dft<5>(float2 *v)
 // product of the radices already applied) and writes out[(j - k) R + k + t Ns].  tw[m] = e^{-2 pi i m / N}.
 // (No integer division in the loop: the GPU has none in hardware and two of them doubled the instruction count of a
 // butterfly.  M and tstep come with the plan; j mod Ns is a multiply-high by ceil(2^32 / Ns), exact while j Ns < 2^32.)
+// IN PLACE: every butterfly of the pass is read (and transformed) into registers, a barrier, then written back to the
+// SAME buffer - two barriers per pass instead of one, but half the LDS per sequence, and these passes live on occupancy
+// (a phase gives a thread about one butterfly between barriers; round 4: 5 -> 8 workgroups per CU for the 1080p rows).
+// A thread holds ceil(M / NT) butterflies: at most MAXN / (R * NT) of R points, MAXN / NT complex values in all; the size
+// class above 2048 points runs 512 threads per workgroup so that the register file of a pass stays the same.
+// MAXN = the size class of the transform (2048 or 4096): it sizes the register file of a pass.
+template <int R, int MAXN, int NT>
+__device__ __forceinline__ void fft_pass(float2 *__restrict__ buf, const float2 *__restrict__ tw, int N, int Ns,
+                                         uint32_t ns_magic, int M, int tstep, int cols, int tid)
+{
+    constexpr int IT = (MAXN / R + NT - 1) / NT;
+    for (int c = 0; c < cols; c++) {
+        float2 v[IT][R];
+        int dsto[IT];
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int j = tid + it * NT;
+            if (j < M) {
+                const int k = Ns == 1 ? 0 : j - (int)__umulhi((uint32_t)j, ns_magic) * Ns; // j mod Ns  (Ns == 1: wave-uniform)
+                const float2 *src = buf + c * N + j;
+                v[it][0] = src[0];
+#pragma unroll
+                for (int t = 1; t < R; t++) v[it][t] = cmul(src[t * M], tw[t * k * tstep]);
+                dft<R>(v[it]);
+                dsto[it] = c * N + (j - k) * R + k;
+            }
+        }
+        __syncthreads(); // every butterfly of the pass has been read
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int j = tid + it * NT;
+            if (j < M) {
+                float2 *dst = buf + dsto[it];
+#pragma unroll
+                for (int t = 0; t < R; t++) dst[t * Ns] = v[it][t];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// all passes of a plan, in place in `buf` (cols sequences of P.n <= MAXN back to back); NT threads
+template <int MAXN, int NT>
+__device__ __forceinline__ void fft_run(const dct_fft_plan &P, float2 *buf, const float2 *tw, int cols, int tid)
+{
+    int Ns = 1;
+    for (int p = 0; p < P.npass; p++) {
+        const int R = P.radix[p];
+        const uint32_t mg = P.ns_magic[p];
+        const int M = P.m[p], ts = P.tstep[p];
+        if (R == 8) fft_pass<8, MAXN, NT>(buf, tw, P.n, Ns, mg, M, ts, cols, tid);
+        else if (R == 4) fft_pass<4, MAXN, NT>(buf, tw, P.n, Ns, mg, M, ts, cols, tid);
+        else if (R == 2) fft_pass<2, MAXN, NT>(buf, tw, P.n, Ns, mg, M, ts, cols, tid);
+        else if (R == 3) fft_pass<3, MAXN, NT>(buf, tw, P.n, Ns, mg, M, ts, cols, tid);
+        else fft_pass<5, MAXN, NT>(buf, tw, P.n, Ns, mg, M, ts, cols, tid);
+        Ns *= R;
+    }
+}
+
+// The column pass keeps the OUT-OF-PLACE form (two buffers, one barrier per pass): it is bound by its strided global
+// reads, not by occupancy, and the second barrier of the in-place form cost it 2-17 % (720p 0.59 -> 0.70 ms, 2160p 5.5 -> 6.4).
 template <int R>
-__device__ __forceinline__ void fft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
+__device__ __forceinline__ void fft_pass_oop(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ tw,
                                          int N, int Ns, uint32_t ns_magic, int M, int tstep, int cols, int tid, int nthreads)
 {
     for (int c = 0; c < cols; c++)
@@ -108,7 +171,7 @@ __device__ __forceinline__ void fft_pass(const float2 *__restrict__ in, float2 *
 }
 
 // all passes of a plan; returns the buffer that holds the (naturally ordered) spectrum
-__device__ __forceinline__ float2 *fft_run(const dct_fft_plan &P, float2 *b0, float2 *b1, const float2 *tw, int cols, int tid,
+__device__ __forceinline__ float2 *fft_run_oop(const dct_fft_plan &P, float2 *b0, float2 *b1, const float2 *tw, int cols, int tid,
                                            int nthreads)
 {
     float2 *in = b0, *out = b1;
@@ -117,11 +180,11 @@ __device__ __forceinline__ float2 *fft_run(const dct_fft_plan &P, float2 *b0, fl
         const int R = P.radix[p];
         const uint32_t mg = P.ns_magic[p];
         const int M = P.m[p], ts = P.tstep[p];
-        if (R == 8) fft_pass<8>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
-        else if (R == 4) fft_pass<4>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
-        else if (R == 2) fft_pass<2>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
-        else if (R == 3) fft_pass<3>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
-        else fft_pass<5>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        if (R == 8) fft_pass_oop<8>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        else if (R == 4) fft_pass_oop<4>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        else if (R == 2) fft_pass_oop<2>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        else if (R == 3) fft_pass_oop<3>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
+        else fft_pass_oop<5>(in, out, tw, P.n, Ns, mg, M, ts, cols, tid, nthreads);
         __syncthreads();
         float2 *t = in; in = out; out = t;
         Ns *= R;
@@ -141,16 +204,16 @@ __device__ __forceinline__ float2 dct_from_fft(const float2 *Z, int k, int N, fl
     return make_float2(post.x * ax + post.y * ay, post.x * bx + post.y * by);
 }
 
-// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = 2 NSEQ * w * 8 bytes; rows_per_wg is even.
+// grid = (ceil(h / rows_per_wg), n_frames), block = 256, dynamic LDS = NSEQ * w * 8 bytes (the passes run in place); rows_per_wg is even.
 // One FFT transforms a PAIR of rows of the SAME plane (row r in the real part, row r + 1 in the imaginary part); with
 // NSEQ = 2 the pair of the plane and the pair of prev - curr go through the passes together (half the barriers per row).
-template <int NSEQ>
-__global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride, int h,
+template <int NSEQ, int MAXN, int NT>
+__global__ __launch_bounds__(NT) void k_dct_fft_rows(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride, int h,
                                                       int w, dct_fft_plan P, float *__restrict__ Ra, float *__restrict__ Rb,
                                                       int rows_per_wg, int want_a, int want_b)
 {
     extern __shared__ float2 lds_fft[];
-    float2 *b0 = lds_fft, *b1 = lds_fft + NSEQ * w;
+    float2 *b0 = lds_fft;
     // twiddles come from the plan's table in global memory (L1-resident): a copy in LDS cost 15 KB per workgroup, i.e. two of
     // the five workgroups a CU can hold, and these passes live on occupancy (1.00 ms with the copy, 0.90 without, 1080p)
     const float2 *tw = P.tw;
@@ -168,7 +231,7 @@ __global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict_
             for (int q = 0; q < ns; q++) {
                 const int pl = which[p0 + q];
                 float2 *dst = b0 + q * w;
-                for (int n = tid; n < w; n += 256) {
+                for (int n = tid; n < w; n += NT) {
                     const int c0 = cur[(int64_t)r * pitch + n], c1 = cur[(int64_t)(r + 1) * pitch + n];
                     float2 v;
                     if (pl == 0) v = make_float2((float)(c0 - 128), (float)(c1 - 128));
@@ -177,12 +240,13 @@ __global__ __launch_bounds__(256) void k_dct_fft_rows(const uint8_t *__restrict_
                 }
             }
             __syncthreads();
-            const float2 *Z = fft_run(P, b0, b1, tw, ns, tid, 256); // ONE call site for every mask
+            fft_run<MAXN, NT>(P, b0, tw, ns, tid); // ONE call site for every mask
+            const float2 *Z = b0;
             for (int q = 0; q < ns; q++) {
                 const int pl = which[p0 + q];
                 float *o0 = (pl ? Rb : Ra) + ((int64_t)f * h + r) * w, *o1 = o0 + w;
                 const float add = pl ? 0.f : dc;
-                for (int k = tid; k < w; k += 256) {
+                for (int k = tid; k < w; k += NT) {
                     const float2 c = dct_from_fft(Z + q * w, k, w, P.post[k]);
                     o0[k] = k ? c.x : c.x + add;
                     o1[k] = k ? c.y : c.y + add;
@@ -236,7 +300,7 @@ __global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ 
         __syncthreads(); // the previous round's readers are done
         for (int q = 0; q < ns; q++) load(which[p0 + q] ? pb : pa, b0 + q * h);
         __syncthreads();
-        const float2 *Z = fft_run(P, b0, b1, twl, ns, tid, 256);
+        const float2 *Z = fft_run_oop(P, b0, b1, twl, ns, tid, 256);
         for (int q = 0; q < ns; q++) reduce(Z + q * h, which[p0 + q] == 0);
     }
     const double es = block_sum(e, red);
@@ -251,7 +315,7 @@ __global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ 
 // radix-8 passes first, then 4, 2, 3, 5; false if n is odd, has another prime factor, or is too short / too long to pay
 bool dct_fft_factor(int n, int radix[DCT_FFT_MAX_PASSES], int *npass)
 {
-    if (n < 128 || n > 4000 || (n & 1)) return false; // (two buffers of n float2 within 64 KiB of LDS)
+    if (n < 128 || n > 4000 || (n & 1)) return false; // (two sequences of n float2 within 64 KiB of LDS; FFT_MAXN registers)
     int m = n, np = 0;
     while (m % 8 == 0 && np < DCT_FFT_MAX_PASSES) { radix[np++] = 8; m /= 8; }
     while (m % 4 == 0 && np < DCT_FFT_MAX_PASSES) { radix[np++] = 4; m /= 4; }
@@ -289,8 +353,12 @@ void launch_dct_full_fft(hipStream_t st, const uint8_t *planes, int pitch, int64
     const dim3 gr((h + rpw - 1) / rpw, n);
     // (NSEQ = 2 - both planes' row pairs through the passes together - measured SLOWER at every size: 1080p 1.52 ms against
     // 1.11, 720p 0.45 against 0.37, 540p 0.22 against 0.20: larger LDS footprint, fewer workgroups per CU)
-    hipLaunchKernelGGL((k_dct_fft_rows<1>), gr, dim3(256), (size_t)2 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb, rpw,
-                       (int)energy, (int)temporal);
+    if (w <= 2048)
+        hipLaunchKernelGGL((k_dct_fft_rows<1, 2048, 256>), gr, dim3(256), (size_t)w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb,
+                           rpw, (int)energy, (int)temporal);
+    else
+        hipLaunchKernelGGL((k_dct_fft_rows<1, 4096, 512>), gr, dim3(512), (size_t)w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb,
+                           rpw, (int)energy, (int)temporal);
     const int tiles = w >> 1;
     const dim3 gc((tiles + 7) / 8 * 8, n);
     if (4 * h * 8 <= cap - 64)
