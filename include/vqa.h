@@ -89,7 +89,10 @@ typedef enum vqa_mem_kind {
 /* motion_mode (what VQA_M_MOTION computes) */
 #define VQA_MOTION_SAD       0 /* 16x16 block-SAD full search (north_star; default)          */
 #define VQA_MOTION_FARNEBACK 1 /* cv2.calcOpticalFlowFarneback(.., 0.5, 3, 15, 3, 5, 1.2, 0)
-                                  mean magnitude — what the reference computes (:340-343)     */
+                                  mean magnitude — what the reference computes (:340-343).
+                                  Scratch on the device: 52 bytes per pixel and pair of a chunk,
+                                  chunks of up to 12 GiB (64 pairs of 1080p = 6.9 GB), kept by
+                                  the ctx until vqa_destroy                                   */
 
 /* ssim_mode */
 #define VQA_SSIM_GAUSS  0 /* 11x11 Gaussian window, sigma 1.5 (north_star)                  */
@@ -225,7 +228,7 @@ enum vqa_kernel_id {
     VQA_K_SSIM_GAUSS = 7,
     VQA_K_SSIM_FFMPEG = 8,
     VQA_K_ORB = 9,       /* FAST-9/16 + NMS on the 64x64 thumbnail's centre */
-    VQA_K_FARNEBACK = 10, /* the whole Farneback pyramid (about 45 launches per chunk of pairs) */
+    VQA_K_FARNEBACK = 10, /* the whole Farneback pyramid (about 30 launches per chunk of pairs) */
     VQA_K_COUNT = 11
 };
 /* When enabled, every kernel launch made by a submit call is bracketed by a
