@@ -12,16 +12,20 @@
 // this translation unit is compiled with floating-point contraction OFF, so the float planes (blurred
 // images, expansions, products) are bit-identical to the oracle's: the 2x2 solve is ill-conditioned wherever
 // the image is flat or has a single orientation, and a fused multiply-add in the products would show up
-// in the flow there.  (The double box sums differ from the oracle's tap order at the 1e-16 level only.)
+// in the flow there.  (The vertical box sums follow the oracle's order exactly; the horizontal ones differ from it at the
+// 1e-16 level only.)
 //
-// Structure per pyramid level (coarse to fine), for a chunk of frame pairs whose planes stay resident:
-//   k_fb_blur_h / k_fb_blur_v : float(gray) -> separable Gaussian, BORDER_REFLECT_101   (per plane, shared
-//   k_fb_resize               : INTER_LINEAR float resize (2x2 mean when exactly halving)  by both pairs
-//   k_fb_polyexp              : 11x11 polynomial expansion -> 5 coefficients per pixel      it belongs to)
-//   (the coarser level's flow is upsampled and doubled inside the level's first k_fb_update)
-//   k_fb_update               : bilinear warp of the second expansion by the flow -> 5 products per pixel
-//   k_fb_blur_solve           : 15x15 box sums (double, replicated border) + regularised 2x2 solve -> flow
+// Structure per pyramid level (coarse to fine), for a chunk of frame pairs whose planes stay resident (round 4):
+//   k_fb_level    : float(gray) -> separable Gaussian (BORDER_REFLECT_101) -> INTER_LINEAR resize to the level  (per plane,
+//                   (2x2 mean when exactly halving), ONE kernel, only the samples the level reads                  shared by
+//   k_fb_polyexp  : 11x11 polynomial expansion -> 5 coefficient PLANES per gray plane                              both pairs)
+//   k_fb_resize<2>: the coarser level's flow upsampled and doubled (once per level)
+//   k_fb_iter     : one flow iteration = bilinear warp of the second expansion by the flow -> 5 products per pixel
+//                   (registers only) -> 15x15 box sums in double, OpenCV's running column sums -> regularised 2x2 solve
 // and k_fb_mag for the mean magnitude.  All of it is stencil work on fp32 planes: HBM / LDS / VALU, no MFMA.
+// The kernels of rounds 2-3 (k_fb_blur_h / k_fb_blur_v / k_fb_resize<1> as three passes: the fallback for a level whose
+// patch exceeds the LDS budget; k_fb_update + k_fb_blur_solve with the products through HBM: lab build only) are kept
+// below next to what replaced them; LAB_NOTES.md L6 has the measurements.
 #pragma clang fp contract(off)
 #include "vqa_dev.hpp"
 #include "vqa_kernels.hpp"
