@@ -23,4 +23,13 @@ for k in sorted(vals["FETCH_SIZE"]):
     tot += b
     print("%-22s %8.1f B per level-0 pixel-pair (fetch %.1f, write %.1f)" % (k, b / P, 2 * vals["FETCH_SIZE"][k] * 1024 / P, vals["WRITE_SIZE"].get(k, 0) * 1024 / P))
 print("total %.1f B per level-0 pixel-pair" % (tot / P))
+import json, subprocess
+out = {"what": "HBM bytes of the Farneback kernels, scripts/fb_only.py (3 launches of 32 pairs of 1080p), per level-0 pixel and pair, "
+               "summed over the four pyramid levels; hbm = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM section)",
+       "git_sha": os.environ.get("VQA_GIT_SHA", ""), "pixel_pairs": P,
+       "kernels": {k: {"fetch_B_per_px_pair": round(2 * vals["FETCH_SIZE"][k] * 1024 / P, 2),
+                       "write_B_per_px_pair": round(vals["WRITE_SIZE"].get(k, 0) * 1024 / P, 2)}
+                   for k in sorted(vals["FETCH_SIZE"]) if k.startswith("k_fb")},
+       "total_B_per_px_pair": round(tot / P, 1)}
+json.dump(out, open(os.path.join(root, "gpurun_out", "fb_pmc.json"), "w"), indent=1)
 PY
