@@ -311,6 +311,101 @@ __global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ 
     }
 }
 
+// ---- column pass, round 4 form: EIGHT columns of one plane per workgroup ------------------------------------------
+// The pair-per-workgroup kernel above reads 8 bytes per row at a stride of a whole row: every lane of a load touches its
+// own cache line.  Here a workgroup takes the 32-byte segment (four column pairs) of every row of ONE plane into an LDS
+// slab z[makhoul(row)][pair] (float2: column 2p in the real part, 2p + 1 in the imaginary part), runs the radix passes on
+// the four interleaved sequences IN PLACE (a pass's butterflies of all four sequences go through registers between two
+// barriers: a quarter of the barriers per sequence, and consecutive lanes touch consecutive LDS words), and reduces
+// sum Y^2 (plane a) or sum |Y| (plane b) straight from the slab.  One plane per workgroup (blockIdx.z), so a metric's bits
+// cannot depend on whether the other one was asked for.  LDS = 32 h bytes (1080p: 34.5 KB, four workgroups per CU).
+// grid = (8 * ceil(ceil(w / 8) / 8), n_frames, planes wanted), block = NT; MAXN = size class (register file of a pass).
+// Used up to 2040 rows (64 KiB of LDS); taller planes keep the pair-per-workgroup kernel above.
+template <int R, int MAXN, int NT>
+__device__ __forceinline__ void fft_pass4(float2 *__restrict__ z, const float2 *__restrict__ tw, int Ns, uint32_t ns_magic, int M,
+                                          int tstep, int tid)
+{
+    constexpr int IT = (4 * (MAXN / R) + NT - 1) / NT;
+    float2 v[IT][R];
+    int dsto[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int q = tid + it * NT, c = q & 3, j = q >> 2;
+        if (j < M) {
+            const int k = Ns == 1 ? 0 : j - (int)__umulhi((uint32_t)j, ns_magic) * Ns;
+            const float2 *src = z + j * 4 + c;
+            v[it][0] = src[0];
+#pragma unroll
+            for (int t = 1; t < R; t++) v[it][t] = cmul(src[t * M * 4], tw[t * k * tstep]);
+            dft<R>(v[it]);
+            dsto[it] = ((j - k) * R + k) * 4 + c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int q = tid + it * NT, j = q >> 2;
+        if (j < M) {
+            float2 *dst = z + dsto[it];
+#pragma unroll
+            for (int t = 0; t < R; t++) dst[t * Ns * 4] = v[it][t];
+        }
+    }
+    __syncthreads();
+}
+
+template <int MAXN, int NT>
+__global__ __launch_bounds__(NT) void k_dct_fft_cols8(const float *__restrict__ Ra, const float *__restrict__ Rb, int h, int w,
+                                                       dct_fft_plan P, double *__restrict__ pe, double *__restrict__ pt, int want_a,
+                                                       int want_b, int ntiles)
+{
+    extern __shared__ float2 lds_fft[];
+    __shared__ double red[NT / 64];
+    float2 *z = lds_fft;
+    const float2 *tw = P.tw;
+    const int tid = threadIdx.x, f = blockIdx.y;
+    const bool plane_b = want_a ? blockIdx.z == 1 : true; // z = 0: the first wanted plane
+    (void)want_b;
+    // XCD-aware tile order: XCD c takes a contiguous range of tiles, so the two tiles that share a 64-byte sector meet in ONE L2
+    const int per = ((int)gridDim.x + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles) return;
+    const int x0 = tile * 8, npairs = min(4, (w - x0) >> 1); // w is even
+    const float *src = (plane_b ? Rb : Ra) + (int64_t)f * h * w + x0;
+    for (int i = tid; i < h * 4; i += NT) {
+        const int m = i >> 2, c = i & 3;
+        float2 val = make_float2(0.f, 0.f);
+        if (c < npairs) val = *(const float2 *)(src + (int64_t)m * w + 2 * c); // x0 + 2c is even: 8-byte aligned
+        z[makhoul_pos(m, h) * 4 + c] = val;
+    }
+    __syncthreads();
+    int Ns = 1;
+    for (int p = 0; p < P.npass; p++) {
+        const int R = P.radix[p];
+        const uint32_t mg = P.ns_magic[p];
+        const int M = P.m[p], ts = P.tstep[p];
+        if (R == 8) fft_pass4<8, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
+        else if (R == 4) fft_pass4<4, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
+        else if (R == 2) fft_pass4<2, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
+        else if (R == 3) fft_pass4<3, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
+        else fft_pass4<5, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
+        Ns *= R;
+    }
+    double acc = 0;
+    for (int i = tid; i < h * 4; i += NT) {
+        const int k = i >> 2, c = i & 3;
+        if (c >= npairs) continue;
+        const float2 zk = z[k * 4 + c], zn = z[(k ? h - k : 0) * 4 + c], post = P.post[k];
+        const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y); // as dct_from_fft
+        const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
+        const float y0 = post.x * ax + post.y * ay, y1 = post.x * bx + post.y * by;
+        if (plane_b) acc += (double)fabsf(y0) + (double)fabsf(y1);
+        else acc += (double)y0 * (double)y0 + (double)y1 * (double)y1;
+    }
+    const double tot = block_sum(acc, red);
+    if (tid == 0) (plane_b ? pt : pe)[(int64_t)f * ntiles + tile] = tot;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 // radix-8 passes first, then 4, 2, 3, 5; false if n is odd, has another prime factor, or is too short / too long to pay
 bool dct_fft_factor(int n, int radix[DCT_FFT_MAX_PASSES], int *npass)
@@ -359,12 +454,25 @@ void launch_dct_full_fft(hipStream_t st, const uint8_t *planes, int pitch, int64
     else
         hipLaunchKernelGGL((k_dct_fft_rows<1, 4096, 512>), gr, dim3(512), (size_t)w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb,
                            rpw, (int)energy, (int)temporal);
-    const int tiles = w >> 1;
-    const dim3 gc((tiles + 7) / 8 * 8, n);
-    if (4 * h * 8 <= cap - 64)
-        hipLaunchKernelGGL(k_dct_fft_cols<true>, gc, dim3(256), (size_t)4 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
-    else
-        hipLaunchKernelGGL(k_dct_fft_cols<false>, gc, dim3(256), (size_t)2 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
+    // eight columns of one plane per workgroup (32 h bytes of LDS)
+    int tiles = (w + 7) / 8;
+    const dim3 gc((tiles + 7) / 8 * 8, n, (energy ? 1 : 0) + (temporal ? 1 : 0));
+    if (h <= 1152) {
+        hipLaunchKernelGGL((k_dct_fft_cols8<1152, 256>), gc, dim3(256), (size_t)h * 32, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy,
+                           (int)temporal, tiles);
+    } else if (h <= 2040) {
+        hipLaunchKernelGGL((k_dct_fft_cols8<2048, 256>), gc, dim3(256), (size_t)h * 32, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy,
+                           (int)temporal, tiles);
+    } else {
+        // taller planes: the slab would exceed 64 KiB (2160 rows: 69 KB, ONE 512-thread workgroup per CU - measured 5.8 ms
+        // against 5.6 for the pair-per-workgroup kernel, 64 x 2160p): the pair kernel stays
+        tiles = w >> 1;
+        const dim3 gp((tiles + 7) / 8 * 8, n);
+        if (4 * h * 8 <= cap - 64)
+            hipLaunchKernelGGL(k_dct_fft_cols<true>, gp, dim3(256), (size_t)4 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
+        else
+            hipLaunchKernelGGL(k_dct_fft_cols<false>, gp, dim3(256), (size_t)2 * h * 8, st, Ra, Rb, h, w, ph_, pe, pt, (int)energy, (int)temporal);
+    }
     launch_dct_full_finalize(st, pe, pt, tiles, n, res, energy, temporal, first_has_prev);
 }
 

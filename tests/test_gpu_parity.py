@@ -135,10 +135,12 @@ def test_dct8_constant_frames_known_answer(engine):
     assert rec[0]["temporal_dct_l1"] == 0.0
 
 
-@pytest.mark.parametrize("h,w", [(1080, 1920), (1078, 1918), (720, 1280)])
+@pytest.mark.parametrize("h,w", [(1080, 1920), (1078, 1918), (720, 1280), (1440, 2560), (2160, 3840)])
 def test_dct_full_frame_1080p_native_vs_scipy(engine, h, w):
     """N1: the reference's full-frame temporal DCT at NATIVE resolution (complexity_metrics.py:363-364, :574-579).
-    1080x1920 and 720x1280 factor into 2, 3, 5 and take the FFT-based row / column passes (k_dct_fft.hip); 1078x1918
+    1080x1920 and 720x1280 factor into 2, 3, 5 and take the FFT-based row / column passes (k_dct_fft.hip: rows in place,
+    eight-column slabs; 1440x2560 = the larger register class of both, 2160x3840 = 512-thread rows and the
+    pair-per-workgroup column kernel); 1078x1918
     (= 2 7^2 11 x 2 7 137) does not and takes the fp32 MFMA products (k_dct_full.hip: 128x128 tiles with a ragged edge, the
     prefetch tail and the |.| reduction).  Checker: scipy.fft.dctn(norm="ortho") in float64 (the C oracle's O(N^3) loop
     is too slow at this size)."""
