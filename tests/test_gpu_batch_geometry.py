@@ -98,3 +98,34 @@ def test_c4_batch_64x2160p_at_the_timed_geometry(engine):
 def test_c3_noise_batch_seams(engine):
     """S-noise (worst case for the Canny fan-out and the histogram bins) at 1080p, 48 frames = three DCT chunks."""
     _run_and_check(engine, 1080, 1920, 48, [0, 15, 16, 47], content="noise")
+
+
+def test_c3ref_batch_64x1080p_reference_definitions(engine):
+    """`bench.py --workload c3ref` as a test: 64 device-resident 1080p pairs through the reference's OWN definitions -
+    Farneback motion (one 64-pair chunk: the fused iteration runs 3 row strips x 8 column blocks per pair, the level
+    kernels every tile shape) and the full-frame DCT (in-place FFT rows, eight-column slabs) - against the oracle at both
+    ends and the middle of the batch, plus Parseval and positivity over every frame."""
+    from rtvqa_amd import _native as N
+    h, w, B, positions = 1080, 1920, 64, [0, 1, 32, 63]
+    keep = sorted(set(positions) | set(j + 1 for j in positions))
+    ref_all, dist_all, host = _resident_stream(engine, h, w, B, keep)
+    dist_b, prev0 = dist_all.slice(1, B + 1), dist_all.frame(0)
+
+    def exp(j):
+        return j, check.expected(None, host[j + 1][1], host[j][1], True, (), motion="farneback", dct_mode="full")
+    pool = ThreadPoolExecutor(4)
+    fut = pool.map(exp, positions)
+    params = engine.make_params(dct_mode=N.DCT_FULL, motion_mode=N.MOTION_FARNEBACK)
+    c = engine.complexity(dist_b, prev0=prev0, mask=N.M_ALL, params=params)
+    assert c.shape == (B,) and not c["hyst_overflow"].any() and (c["has_prev"] == 1).all()
+    rel = np.abs(c["dct_energy"] - c["sum_gray2"].astype(np.float64)) / c["sum_gray2"].astype(np.float64)
+    assert rel.max() < check.RTOL                                  # Parseval, every frame
+    assert (c["temporal_dct_l1"] > 0).all() and (c["flow_mag_mean"] > 0).all() and (c["sad_blocks"] == 0).all()
+    bad = {}
+    for j, e in fut:
+        notes = []
+        m = check.compare(e, c[j], None, "gauss", notes=notes)
+        if m or notes:
+            bad[j] = (m, notes)
+    pool.shutdown()
+    assert not bad, bad
