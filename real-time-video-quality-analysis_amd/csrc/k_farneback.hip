@@ -169,6 +169,30 @@ __global__ __launch_bounds__(256) void k_fb_resize(const float *__restrict__ src
     }
     const int x0 = xofs[x], x1 = min(x0 + 1, sw - 1);
     const float a0 = xa[2 * x], a1 = xa[2 * x + 1];
+    if (CN == 2) {
+        // flow fields: pixels are float2 (8-byte aligned: one load per corner, one store per pixel)
+        const float2 *s2 = reinterpret_cast<const float2 *>(s);
+        float2 *d2 = reinterpret_cast<float2 *>(dst) + (int64_t)blockIdx.z * dh * dw + x;
+#pragma unroll 4
+        for (int y = blockIdx.y * FB_RB; y < yend; y++) {
+            const int y0 = min(max(yofs[y], 0), sh - 1), y1 = min(max(yofs[y] + 1, 0), sh - 1);
+            const float b0 = yb[2 * y], b1 = yb[2 * y + 1];
+            const float2 p00 = s2[(int64_t)y0 * sw + x0], p01 = s2[(int64_t)y0 * sw + x1];
+            const float2 p10 = s2[(int64_t)y1 * sw + x0], p11 = s2[(int64_t)y1 * sw + x1];
+            float2 v;
+            {
+                const float r0 = p00.x * a0 + p01.x * a1, r1 = p10.x * a0 + p11.x * a1;
+                v.x = r0 * b0 + r1 * b1;
+            }
+            {
+                const float r0 = p00.y * a0 + p01.y * a1, r1 = p10.y * a0 + p11.y * a1;
+                v.y = r0 * b0 + r1 * b1;
+            }
+            if (apply_mul) { v.x *= mul; v.y *= mul; }
+            d2[(int64_t)y * dw] = v;
+        }
+        return;
+    }
 #pragma unroll 4
     for (int y = blockIdx.y * FB_RB; y < yend; y++) {
         float *d = dst + (((int64_t)blockIdx.z * dh + y) * dw + x) * CN;
@@ -203,6 +227,8 @@ struct fb_level_args {
     const int32_t *sx, *sy;                                           // S = 2: sample coordinates, 2 per level column / row
     const float *xa, *yb; int mode;                                   // S = 2: bilinear weights; mode 1 = 2x2 mean
     int cap_x, cap_y;                                                 // patch capacity (columns incl. 2r, rows incl. 2r)
+    int tsx, tsy;                                                     // samples a tile really uses (<= 64, <= NSY; multiples of S):
+                                                                      // 62 when r = 1, so that the patch is exactly 64 wide / high
 };
 
 static inline size_t fb_level_lds(int cap_x, int cap_y, int nsy)
@@ -223,17 +249,18 @@ __global__ __launch_bounds__(256) void k_fb_level(fb_level_args A, fb_taps T)
     int *sr = sc + 64;                                     // [NSY] sample rows
     unsigned char *u8t = reinterpret_cast<unsigned char *>(sr + NSY); // [cap_y][px]
     const int t = threadIdx.x;
-    const int X0 = blockIdx.x * (64 / S), Y0 = blockIdx.y * (NSY / S);
+    const int X0 = blockIdx.x * (A.tsx / S), Y0 = blockIdx.y * (A.tsy / S);
     const int r = T.ksize >> 1;
     if (t < 32) kk[t] = T.k[t];
     if (t < 64) {
-        if (S == 1) sc[t] = min(X0 + t, A.w - 1);
-        else sc[t] = A.sx[2 * min(X0 + (t >> 1), A.lw - 1) + (t & 1)];
+        const int i = min(t, A.tsx - 1); // the unused sample slots repeat the last one (the patch extent is sc[63] - sc[0])
+        if (S == 1) sc[t] = min(X0 + i, A.w - 1);
+        else sc[t] = A.sx[2 * min(X0 + (i >> 1), A.lw - 1) + (i & 1)];
     }
     if (t >= 64 && t < 64 + NSY) {
-        const int j = t - 64;
-        if (S == 1) sr[j] = min(Y0 + j, A.h - 1);
-        else sr[j] = A.sy[2 * min(Y0 + (j >> 1), A.lh - 1) + (j & 1)];
+        const int j = min(t - 64, A.tsy - 1);
+        if (S == 1) sr[t - 64] = min(Y0 + j, A.h - 1);
+        else sr[t - 64] = A.sy[2 * min(Y0 + (j >> 1), A.lh - 1) + (j & 1)];
     }
     __syncthreads();
     const int xlo = sc[0] - r, ylo = sr[0] - r;
@@ -297,7 +324,7 @@ __global__ __launch_bounds__(256) void k_fb_level(fb_level_args A, fb_taps T)
                 const int j = j0 + 4 * u;
                 if (S == 1) {
                     const int X = X0 + i, Y = Y0 + j;
-                    if (X < A.lw && Y < A.lh) A.out[((int64_t)blockIdx.z * A.lh + Y) * A.lw + X] = a[u];
+                    if (i < A.tsx && j < A.tsy && X < A.lw && Y < A.lh) A.out[((int64_t)blockIdx.z * A.lh + Y) * A.lw + X] = a[u];
                 } else {
                     bt[j * 64 + i] = a[u];
                 }
@@ -311,7 +338,7 @@ __global__ __launch_bounds__(256) void k_fb_level(fb_level_args A, fb_taps T)
         const int ix = t & 31, X = X0 + ix;
         for (int jy = t >> 5; jy < NSY / 2; jy += 8) {
             const int Y = Y0 + jy;
-            if (X >= A.lw || Y >= A.lh) continue;
+            if (2 * ix >= A.tsx || 2 * jy >= A.tsy || X >= A.lw || Y >= A.lh) continue;
             const float *p = bt + (2 * jy) * 64 + 2 * ix;
             float v;
             if (A.mode == 1) {
@@ -784,11 +811,15 @@ bool launch_fb_level(hipStream_t st, const uint8_t *gray, int pitch, int64_t pla
     A.gray = gray; A.pitch = pitch; A.plane_stride = plane_stride; A.h = h; A.w = w;
     A.out = out; A.lh = lh; A.lw = lw;
     A.sx = A.sy = nullptr; A.xa = A.yb = nullptr; A.mode = 0;
+    // r = 1 (the two finest levels of a 0.5 pyramid): 62 samples per tile side, so the patch is 64 x 64 - one pass of the
+    // column loop and two of the row batches instead of two and three
+    const int ts = r <= 1 ? 62 : 64;
     if (!T) {
         A.cap_x = 64 + 2 * r; A.cap_y = 64 + 2 * r;
+        A.tsx = A.tsy = ts;
         const size_t lds = fb_level_lds(A.cap_x, A.cap_y, 64);
         if (lds > 64 * 1024) return false;
-        hipLaunchKernelGGL((k_fb_level<1, 64>), dim3((lw + 63) / 64, (lh + 63) / 64, planes), dim3(256), lds, st, A, K);
+        hipLaunchKernelGGL((k_fb_level<1, 64>), dim3((lw + ts - 1) / ts, (lh + ts - 1) / ts, planes), dim3(256), lds, st, A, K);
         return true;
     }
     if (!T->sx || !T->sy) return false;
@@ -799,10 +830,13 @@ bool launch_fb_level(hipStream_t st, const uint8_t *gray, int pitch, int64_t pla
     A.cap_y = (tall ? T->span_y32 : T->span_y8) + 2 * r;
     const size_t lds = fb_level_lds(A.cap_x, A.cap_y, tall ? 64 : 16);
     if (lds > 64 * 1024) return false;
+    A.tsx = ts;
+    A.tsy = tall ? ts : 16;
+    const int ox = A.tsx / 2, oy = A.tsy / 2; // level pixels per tile
     if (tall)
-        hipLaunchKernelGGL((k_fb_level<2, 64>), dim3((lw + 31) / 32, (lh + 31) / 32, planes), dim3(256), lds, st, A, K);
+        hipLaunchKernelGGL((k_fb_level<2, 64>), dim3((lw + ox - 1) / ox, (lh + oy - 1) / oy, planes), dim3(256), lds, st, A, K);
     else
-        hipLaunchKernelGGL((k_fb_level<2, 16>), dim3((lw + 31) / 32, (lh + 7) / 8, planes), dim3(256), lds, st, A, K);
+        hipLaunchKernelGGL((k_fb_level<2, 16>), dim3((lw + ox - 1) / ox, (lh + oy - 1) / oy, planes), dim3(256), lds, st, A, K);
     return true;
 }
 

@@ -375,7 +375,7 @@ static int get_fb_tabs(vqa_ctx *c, int sh, int sw, int dh, int dw, fb_resize_tab
             bool mono = true;
             for (size_t i = 1; i < v.size(); i++) mono = mono && v[i] >= v[i - 1];
             if (!mono) return -1;
-            for (int a = 0; a < n; a += tile) {
+            for (int a = 0; a < n; a++) { // every window of `tile` consecutive level columns / rows, aligned or not
                 const int b = (a + tile < n ? a + tile : n) - 1;
                 const int e = v[2 * b + 1] - v[2 * a] + 1;
                 m = e > m ? e : m;

@@ -120,7 +120,7 @@ struct fb_resize_tabs { // cv2.resize INTER_LINEAR tables for float data (device
     int32_t *cols = nullptr, *rows = nullptr;
     int nc = 0, nr = 0;
     // the fused level kernel's view of a downscale: the two source columns / rows each level column / row samples
-    // (clamps applied; 2 * dsize entries) and the widest extent of them over tiles of 32 columns, 8 and 32 rows
+    // (clamps applied; 2 * dsize entries) and the widest extent of them over any 32 consecutive columns, 8 and 32 rows
     int32_t *sx = nullptr, *sy = nullptr;
     int span_x32 = 0, span_y8 = 0, span_y32 = 0;
 };
