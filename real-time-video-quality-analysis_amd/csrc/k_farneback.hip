@@ -648,13 +648,12 @@ constexpr int FI_ROWB = 2304;                               // bytes per row: 9 
 constexpr int FI_CHB = FI_R * FI_ROWB + 256;                // bytes per channel
 __device__ __forceinline__ constexpr int fi_row_off(int q) { return q * FI_ROWB + (q & 1) * 16 + (q >> 1) * 128; }
 
+// SRC = 0: the displacement comes from the level's flow field `fin`; SRC = 2: zero (coarsest level, fin unused).
 template <int SRC>
 __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, const float *__restrict__ fin, int h, int w,
-                                                   float *__restrict__ fout, int ch, int cw,
-                                                   const int32_t *__restrict__ xofs, const float *__restrict__ xa,
-                                                   const int32_t *__restrict__ yofs, const float *__restrict__ yb, float mul,
-                                                   int ncb, int QS)
+                                                   float *__restrict__ fout, int ncb, int QS)
 {
+    static_assert(SRC == 0 || SRC == 2, "the in-flight upsample of rounds 2-3 (SRC = 1) lives in the lab build's k_fb_update only");
     static_assert(FI_R == 2 || FI_R == 4, "rows per step = lanes per group = adjacent output columns per lane");
     // two buffers, alternating by step: ONE barrier per step (a step's stores go to the buffer read two steps ago, and every
     // thread passed the barrier in between only after finishing those reads; 16 / FI_R steps per loop iteration is even)
@@ -665,7 +664,7 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
     const int yend = min(ys + QS, h);
     const int64_t P = (int64_t)h * w;
     const float *R0 = R + (int64_t)blockIdx.y * P * 5, *R1 = R0 + P * 5;
-    const float *fp = SRC == 0 ? fin + (int64_t)blockIdx.y * P * 2 : SRC == 1 ? fin + (int64_t)blockIdx.y * ch * cw * 2 : nullptr;
+    const float *fp = SRC == 0 ? fin + (int64_t)blockIdx.y * P * 2 : nullptr;
     float *fo = fout + (int64_t)blockIdx.y * P * 2;
     const int xx = min(max(x0 - BS_M + t, 0), w - 1); // replicated border: the clamped column's products ARE the border's
     float ring[16][5];
@@ -689,7 +688,7 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
     auto row_of = [&](int y) { return min(max(y + BS_M, 0), h - 1); };
     float dxn[FI_R], dyn[FI_R];
 #pragma unroll
-    for (int q = 0; q < FI_R; q++) fb_flow_at<SRC>(fp, w, xx, row_of(ys - 16 + q), ch, cw, xofs, xa, yofs, yb, mul, dxn[q], dyn[q]);
+    for (int q = 0; q < FI_R; q++) fb_flow_at<SRC>(fp, w, xx, row_of(ys - 16 + q), 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, dxn[q], dyn[q]);
     for (int base = 0;; base += 16) {
         const int yb0 = ys - 16 + base;
         if (yb0 >= yend) break;
@@ -708,7 +707,7 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
             }
 #pragma unroll
             for (int q = 0; q < FI_R; q++)
-                fb_flow_at<SRC>(fp, w, xx, row_of(yb0 + i + FI_R + q), ch, cw, xofs, xa, yofs, yb, mul, dxn[q], dyn[q]);
+                fb_flow_at<SRC>(fp, w, xx, row_of(yb0 + i + FI_R + q), 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, dxn[q], dyn[q]);
 #pragma unroll
             for (int q = 0; q < FI_R; q++) {
                 const int y = yb0 + i + q, rho = y + BS_M;
@@ -886,9 +885,9 @@ void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int 
 #endif
 
 // One fused iteration: flow_out = solve(box15x15(products(R, flow))).  flow == nullptr: zero flow (coarsest level).
-// flow_out must not alias the input: neighbours read it while it is written.  (The kernel can also upsample a coarser
-// field in flight - SRC = 1 - but that put eight dependent loads per row on the march's critical path and cost more than
-// writing the upsampled field once with k_fb_resize<2>; not instantiated.)
+// flow_out must not alias the input: neighbours read it while it is written.  (Upsampling the coarser field inside the
+// first iteration, as rounds 2-3 did in k_fb_update<1>, put eight dependent loads per row on the march's critical path and
+// cost more than writing the upsampled field once with k_fb_resize<2>: LAB_NOTES.md L6.)
 void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *flow_out)
 {
     const int ncb = (w + FI_OUT - 1) / FI_OUT;
@@ -908,11 +907,9 @@ void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs
     }
     dim3 grid(ncb * ns, pairs);
     if (flow)
-        hipLaunchKernelGGL(k_fb_iter<0>, grid, dim3(FI_NT), 0, st, R, flow, h, w, flow_out, 0, 0, nullptr, nullptr, nullptr,
-                           nullptr, 0.f, ncb, QS);
+        hipLaunchKernelGGL(k_fb_iter<0>, grid, dim3(FI_NT), 0, st, R, flow, h, w, flow_out, ncb, QS);
     else
-        hipLaunchKernelGGL(k_fb_iter<2>, grid, dim3(FI_NT), 0, st, R, nullptr, h, w, flow_out, 0, 0, nullptr, nullptr, nullptr,
-                           nullptr, 0.f, ncb, QS);
+        hipLaunchKernelGGL(k_fb_iter<2>, grid, dim3(FI_NT), 0, st, R, nullptr, h, w, flow_out, ncb, QS);
 }
 
 int fb_mag_blocks() { return FB_MAG_BLOCKS; }
