@@ -642,11 +642,15 @@ constexpr int FI_NT = 256, FI_OUT = FI_NT - 14;
 #endif
 constexpr int FI_R = FI_ROWS;
 // LDS: vs[channel][row of the step][column] in doubles.  The lanes of a group read the SAME columns of different rows
-// with ds_read_b128, so the rows of a step are staggered by 16-byte slots that the groups' own 32-byte spacing leaves
-// free: row offsets 0, 16, 128, 144 bytes modulo 256.
+// with ds_read_b128, so the rows of a step are staggered: two rows per step - 128 bytes apart modulo 256 (16 lanes = 8 pairs
+// cover 128 bytes of row 0 and the other 128 of row 1); four rows - the 16-byte slots that the groups' own 32-byte spacing
+// leaves free: row offsets 0, 16, 128, 144 bytes modulo 256.
 constexpr int FI_ROWB = 2304;                               // bytes per row: 9 * 256 >= (256 + 3 + 2) * 8
 constexpr int FI_CHB = FI_R * FI_ROWB + 256;                // bytes per channel
-__device__ __forceinline__ constexpr int fi_row_off(int q) { return q * FI_ROWB + (q & 1) * 16 + (q >> 1) * 128; }
+__device__ __forceinline__ constexpr int fi_row_off(int q)
+{
+    return FI_R == 2 ? q * (FI_ROWB + 128) : q * FI_ROWB + (q & 1) * 16 + (q >> 1) * 128;
+}
 
 // SRC = 0: the displacement comes from the level's flow field `fin`; SRC = 2: zero (coarsest level, fin unused).
 template <int SRC>
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
     double vsum[5] = {0., 0., 0., 0., 0.};
     // horizontal role: output columns k0 .. k0 + FI_R - 1 (relative to x0) of row (t % FI_R) of the step
     const int k0 = t & ~(FI_R - 1), hrow = t & (FI_R - 1);
-    const int vrow = (hrow * FI_ROWB + (hrow & 1) * 16 + (hrow >> 1) * 128) + k0 * 8;
+    const int vrow = (FI_R == 2 ? hrow * (FI_ROWB + 128) : hrow * FI_ROWB + (hrow & 1) * 16 + (hrow >> 1) * 128) + k0 * 8;
     bool outk[FI_R];
 #pragma unroll
     for (int j = 0; j < FI_R; j++) outk[j] = k0 + j < FI_OUT && x0 + k0 + j < w;
