@@ -666,6 +666,23 @@ def test_farneback_known_translation_1080p(engine):
         assert (rec[k] == ref[k]).all(), k
 
 
+def test_farneback_does_not_depend_on_the_batch_it_rides_in(engine):
+    """The fused flow iteration picks its row-strip count from the batch (residency rounds x rows marched): a pair submitted
+    alone marches many short strips, the same pair inside a 40-pair batch a few long ones, and a lower strip restarts its
+    column sums instead of carrying OpenCV's running sum down the frame.  The metric must not care: 1e-6 between the two
+    submissions (and 1e-4 against the oracle, checked elsewhere); identical pairs inside one batch are bit-identical."""
+    from rtvqa_amd import _native as N
+    fr = _frames("natural", 2, 540, 960, seed=31)
+    alone = engine.complexity(fr[1:2], prev0=fr[0], mask=N.M_MOTION, motion_mode=N.MOTION_FARNEBACK)
+    # 40 pairs: even slots hold frame 0, odd slots frame 1 -> every pair is (0 -> 1) or (1 -> 0)
+    rep = np.stack([fr[i & 1] for i in range(41)])
+    many = engine.complexity(rep[1:], prev0=rep[0], mask=N.M_MOTION, motion_mode=N.MOTION_FARNEBACK)
+    a = float(alone[0]["flow_mag_mean"])
+    fwd = many["flow_mag_mean"][0::2]
+    assert a > 0 and (fwd == fwd[0]).all() and (many["flow_mag_mean"][1::2] == many["flow_mag_mean"][1]).all()
+    assert abs(float(fwd[0]) - a) <= 1e-6 * a, (float(fwd[0]), a)
+
+
 def test_many_small_frames_one_batch(engine):
     """Thousands of frames in one submit (frames ride in gridDim.y; per-frame lists, counters, partials)."""
     from rtvqa_amd import _native as N
