@@ -65,7 +65,7 @@ WORKLOADS = {
                name="1920x1080 full suite (motion-SAD, DCT, temporal-DCT, Canny, ORB count, gray+colour hist) + PSNR/SSIM"),
     "c4": dict(h=2160, w=3840, batch=64, full=True, name="3840x2160 full suite + PSNR/SSIM"),
     "c3ref": dict(h=1080, w=1920, batch=64, full=True,
-                  defaults=dict(motion="farneback", dct_mode="full", ssim_mode="ffmpeg", pixfmt="yuv420p", streams=2),
+                  defaults=dict(motion="farneback", dct_mode="full", ssim_mode="ffmpeg", pixfmt="yuv420p", streams=2, inflight=1),
                   name="1920x1080 reference-true suite (Farneback motion, full-frame DCT + temporal DCT, Canny, ORB count, "
                        "gray+colour hist) + FFmpeg psnr/vf_ssim on yuv420p planes"),
 }
@@ -361,7 +361,7 @@ def main():
                          "second context of the device (default for c3ref)")
     ap.add_argument("--inflight", type=int, default=None, choices=[1, 2, 3, 4],
                     help="batches in flight: step i+1 is submitted before step i is waited for, each on its own set of "
-                         "contexts (default 2)")
+                         "contexts (default 2; 1 with Farneback motion - GiB-sized scratch per context)")
     ap.add_argument("--pixfmt", default=None, choices=["bgr24", "yuv420p"],
                     help="planes PSNR/SSIM compare: bgr24 (default: B,G,R of the packed frames) or yuv420p (Y + "
                          "quarter-size U,V derived from the same frames: what FFmpeg compares for an H.264 clip)")
@@ -397,10 +397,9 @@ def main():
         if getattr(args, k) is None:
             setattr(args, k, v)
     if args.inflight is None:
-        # two batches in flight, as a host that streams batches runs (rounds 3-4 kept ONE for Farneback motion: with the
-        # products through HBM and 3 GiB chunks a second batch thrashed, 1684 against 2946 fps; with the fused iteration
-        # it is worth +2 %: c3ref 4493 -> 4580)
-        args.inflight = 2
+        # Farneback keeps GiB-sized scratch per context and saturates the chip on its own: a second batch in flight
+        # thrashes (measured: c3 + Farneback 2946 fps with one batch in flight, 1684 with two)
+        args.inflight = 1 if args.motion == "farneback" else 2
     h, w, full = wl["h"], wl["w"], wl["full"]
     B = args.batch or wl["batch"]
     stub = args.stub_engine

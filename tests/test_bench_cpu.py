@@ -41,7 +41,7 @@ def test_default_workload_is_the_headline_config():
 
 def test_workload_defaults_and_overrides_resolve_in_the_line():
     """The product's configuration is the default (overlap on, two batches in flight on one context each); c3ref and the
-    every mode keeps two batches in flight; explicit flags win; --steps 0 prints a line instead of crashing."""
+    Farneback mode keep one batch in flight; explicit flags win; --steps 0 prints a line instead of crashing."""
     def cfg(*extra):
         r = _run([sys.executable, "bench.py", "--stub-engine", "--backend", "gloo", "--steps", "1", "--warmup", "0", *extra])
         assert r.returncode == 0, r.stderr[-800:]
@@ -51,8 +51,8 @@ def test_workload_defaults_and_overrides_resolve_in_the_line():
         (True, 1, 2, "sad", "block8", "gauss", "bgr24")
     c = cfg("--workload", "c3ref")["config"]
     assert (c["id"], c["streams"], c["inflight"], c["motion"], c["dct_mode"], c["ssim_mode"], c["pixfmt"]) == \
-        ("c3ref", 2, 2, "farneback", "full", "ffmpeg", "yuv420p")
-    assert cfg("--motion", "farneback")["config"]["inflight"] == 2 and cfg("--dct-mode", "full")["config"]["inflight"] == 2
+        ("c3ref", 2, 1, "farneback", "full", "ffmpeg", "yuv420p")
+    assert cfg("--motion", "farneback")["config"]["inflight"] == 1 and cfg("--dct-mode", "full")["config"]["inflight"] == 2
     c = cfg("--no-overlap", "--inflight", "3", "--streams", "2", "--workload", "c3ref", "--motion", "sad")["config"]
     assert (c["overlap"], c["inflight"], c["streams"], c["motion"]) == (False, 3, 2, "sad")
     line = cfg("--steps", "0")
