@@ -398,7 +398,8 @@ def main():
             setattr(args, k, v)
     if args.inflight is None:
         # Farneback keeps GiB-sized scratch per context and saturates the chip on its own: a second batch in flight
-        # thrashes (measured: c3 + Farneback 2946 fps with one batch in flight, 1684 with two)
+        # thrashed in round 3 (c3 + Farneback 2946 fps with one batch in flight, 1684 with two) and is within the
+        # box-to-box noise with round 4's fused iteration (c3ref 4493 -> 4580 over 10 steps, 4435 -> 4354 over 3)
         args.inflight = 1 if args.motion == "farneback" else 2
     h, w, full = wl["h"], wl["w"], wl["full"]
     B = args.batch or wl["batch"]
