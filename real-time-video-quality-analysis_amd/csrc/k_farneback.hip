@@ -633,7 +633,10 @@ __global__ __launch_bounds__(BS_NT) void k_fb_blur_solve(const float *__restrict
 // differs at the 1e-16 level only.  Products are never written: per pixel the iteration reads 20 B (R0) + 20 B (R1,
 // gathered) + 8 B (flow) and writes 8 B.
 // grid = (ncb * ns, pairs), block = FI_NT; QS = rows per strip, a multiple of 16 (static ring slots)
-constexpr int FI_NT = 256, FI_OUT = FI_NT - 14;
+#ifndef FI_THREADS
+#define FI_THREADS 256 // columns per workgroup (256 = shipped; 64 = measurement build: one free-running wave per workgroup)
+#endif
+constexpr int FI_NT = FI_THREADS, FI_OUT = FI_NT - 14;
 #ifndef FB_PROBE
 #define FB_PROBE 0 // measurement builds only (scripts/build_probes.sh FB_PROBE 2): 2 = no products (constant instead)
 #endif
@@ -645,7 +648,7 @@ constexpr int FI_R = FI_ROWS;
 // with ds_read_b128, so the rows of a step are staggered: two rows per step - 128 bytes apart modulo 256 (16 lanes = 8 pairs
 // cover 128 bytes of row 0 and the other 128 of row 1); four rows - the 16-byte slots that the groups' own 32-byte spacing
 // leaves free: row offsets 0, 16, 128, 144 bytes modulo 256.
-constexpr int FI_ROWB = 2304;                               // bytes per row: 9 * 256 >= (256 + 3 + 2) * 8
+constexpr int FI_ROWB = ((FI_NT + 5) * 8 + 255) / 256 * 256;  // bytes per row: a multiple of 256 >= (FI_NT + 3 + 2) * 8  (2304 for 256 columns)
 constexpr int FI_CHB = FI_R * FI_ROWB + 256;                // bytes per channel
 __device__ __forceinline__ constexpr int fi_row_off(int q)
 {
@@ -905,7 +908,8 @@ void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs
         long long best = -1;
         for (int n = 1; n <= cap; n++) {
             const int qs = ((h + n - 1) / n + 15) / 16 * 16, ne = (h + qs - 1) / qs;
-            const long long blocks = (long long)ncb * ne * pairs, cost = ((blocks + 767) / 768) * (qs + 16);
+            constexpr int RES = 768 * 256 / FI_NT; // workgroups resident at once (3 waves per SIMD)
+            const long long blocks = (long long)ncb * ne * pairs, cost = ((blocks + RES - 1) / RES) * (qs + 16);
             if (best < 0 || cost < best) { best = cost; ns = ne; QS = qs; }
         }
     }
