@@ -321,34 +321,35 @@ __global__ __launch_bounds__(256) void k_dct_fft_cols(const float *__restrict__ 
 // cannot depend on whether the other one was asked for.  LDS = 32 h bytes (1080p: 34.5 KB, four workgroups per CU).
 // grid = (8 * ceil(ceil(w / 8) / 8), n_frames, planes wanted), block = NT; MAXN = size class (register file of a pass).
 // Used up to 2040 rows (64 KiB of LDS); taller planes keep the pair-per-workgroup kernel above.
-template <int R, int MAXN, int NT>
-__device__ __forceinline__ void fft_pass4(float2 *__restrict__ z, const float2 *__restrict__ tw, int Ns, uint32_t ns_magic, int M,
+template <int R, int MAXN, int NT, int NS>
+__device__ __forceinline__ void fft_passN(float2 *__restrict__ z, const float2 *__restrict__ tw, int Ns, uint32_t ns_magic, int M,
                                           int tstep, int tid)
 {
-    constexpr int IT = (4 * (MAXN / R) + NT - 1) / NT;
+    static_assert(NS == 2 || NS == 4, "interleaved sequences");
+    constexpr int IT = (NS * (MAXN / R) + NT - 1) / NT;
     float2 v[IT][R];
     int dsto[IT];
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-        const int q = tid + it * NT, c = q & 3, j = q >> 2;
+        const int q = tid + it * NT, c = q & (NS - 1), j = q / NS;
         if (j < M) {
             const int k = Ns == 1 ? 0 : j - (int)__umulhi((uint32_t)j, ns_magic) * Ns;
-            const float2 *src = z + j * 4 + c;
+            const float2 *src = z + j * NS + c;
             v[it][0] = src[0];
 #pragma unroll
-            for (int t = 1; t < R; t++) v[it][t] = cmul(src[t * M * 4], tw[t * k * tstep]);
+            for (int t = 1; t < R; t++) v[it][t] = cmul(src[t * M * NS], tw[t * k * tstep]);
             dft<R>(v[it]);
-            dsto[it] = ((j - k) * R + k) * 4 + c;
+            dsto[it] = ((j - k) * R + k) * NS + c;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-        const int q = tid + it * NT, j = q >> 2;
+        const int q = tid + it * NT, j = q / NS;
         if (j < M) {
             float2 *dst = z + dsto[it];
 #pragma unroll
-            for (int t = 0; t < R; t++) dst[t * Ns * 4] = v[it][t];
+            for (int t = 0; t < R; t++) dst[t * Ns * NS] = v[it][t];
         }
     }
     __syncthreads();
@@ -384,11 +385,11 @@ __global__ __launch_bounds__(NT) void k_dct_fft_cols8(const float *__restrict__ 
         const int R = P.radix[p];
         const uint32_t mg = P.ns_magic[p];
         const int M = P.m[p], ts = P.tstep[p];
-        if (R == 8) fft_pass4<8, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
-        else if (R == 4) fft_pass4<4, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
-        else if (R == 2) fft_pass4<2, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
-        else if (R == 3) fft_pass4<3, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
-        else fft_pass4<5, MAXN, NT>(z, tw, Ns, mg, M, ts, tid);
+        if (R == 8) fft_passN<8, MAXN, NT, 4>(z, tw, Ns, mg, M, ts, tid);
+        else if (R == 4) fft_passN<4, MAXN, NT, 4>(z, tw, Ns, mg, M, ts, tid);
+        else if (R == 2) fft_passN<2, MAXN, NT, 4>(z, tw, Ns, mg, M, ts, tid);
+        else if (R == 3) fft_passN<3, MAXN, NT, 4>(z, tw, Ns, mg, M, ts, tid);
+        else fft_passN<5, MAXN, NT, 4>(z, tw, Ns, mg, M, ts, tid);
         Ns *= R;
     }
     double acc = 0;
@@ -405,6 +406,78 @@ __global__ __launch_bounds__(NT) void k_dct_fft_cols8(const float *__restrict__ 
     const double tot = block_sum(acc, red);
     if (tid == 0) (plane_b ? pt : pe)[(int64_t)f * ntiles + tile] = tot;
 }
+
+#ifndef DCT_ROWS2
+#define DCT_ROWS2 0 // 1 = measurement build (scripts/build_probes.sh DCT_ROWS2 1): two row pairs per transform round
+#endif
+#if DCT_ROWS2
+// ---- row pass, two row pairs per transform round --------------------------------------------------------------------
+// As k_dct_fft_rows, but TWO row pairs of the same plane (rows r..r+1 and r+2..r+3) go through the passes together as
+// two interleaved sequences z[makhoul(n)][pair] (the form of the column pass above): half the barriers per sequence and
+// twice the independent butterflies per thread between them.  LDS = 2 w 8 bytes (30 KB at 1920: five workgroups per CU).
+// MEASURED SLOWER than one pair per round (1080p 0.92 against 0.79 ms per 64 frames, 720p 0.38 against 0.33: 94 VGPRs and
+// 30 KB leave five workgroups per CU where the single-pair kernel has eight): kept as a measurement build only.
+// grid = (ceil(h / rows_per_wg), n_frames), block = NT; rows_per_wg a multiple of 4.
+template <int MAXN, int NT>
+__global__ __launch_bounds__(NT) void k_dct_fft_rows2(const uint8_t *__restrict__ planes, int pitch, int64_t plane_stride, int h,
+                                                       int w, dct_fft_plan P, float *__restrict__ Ra, float *__restrict__ Rb,
+                                                       int rows_per_wg, int want_a, int want_b)
+{
+    extern __shared__ float2 lds_fft[];
+    float2 *z = lds_fft;
+    const float2 *tw = P.tw;
+    const int tid = threadIdx.x, f = blockIdx.y;
+    const uint8_t *cur = planes + (int64_t)(f + 1) * plane_stride, *prev = planes + (int64_t)f * plane_stride;
+    const float dc = 128.f * sqrtf((float)w); // row-DCT of the constant that was subtracted
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
+    int which[2], np_ = 0; // 0: the plane itself (centred), 1: prev - curr
+    if (want_a) which[np_++] = 0;
+    if (want_b) which[np_++] = 1;
+    for (int r = r0; r < r1; r += 4) {          // h is even: a round holds one or two row pairs
+        const int npair = min(2, (r1 - r) >> 1);
+        for (int p0 = 0; p0 < np_; p0++) {
+            const int pl = which[p0];
+            __syncthreads(); // the previous round's readers are done
+            for (int i = tid; i < 2 * w; i += NT) {
+                const int q = i >= w, n = i - q * w, row = r + 2 * q;
+                float2 v = make_float2(0.f, 0.f);
+                if (q < npair) {
+                    const int c0 = cur[(int64_t)row * pitch + n], c1 = cur[(int64_t)(row + 1) * pitch + n];
+                    if (pl == 0) v = make_float2((float)(c0 - 128), (float)(c1 - 128));
+                    else v = make_float2((float)((int)prev[(int64_t)row * pitch + n] - c0), (float)((int)prev[(int64_t)(row + 1) * pitch + n] - c1));
+                }
+                z[makhoul_pos(n, w) * 2 + q] = v;
+            }
+            __syncthreads();
+            int Ns = 1;
+            for (int p = 0; p < P.npass; p++) { // ONE call site of the passes for every mask
+                const int R = P.radix[p];
+                const uint32_t mg = P.ns_magic[p];
+                const int M = P.m[p], ts = P.tstep[p];
+                if (R == 8) fft_passN<8, MAXN, NT, 2>(z, tw, Ns, mg, M, ts, tid);
+                else if (R == 4) fft_passN<4, MAXN, NT, 2>(z, tw, Ns, mg, M, ts, tid);
+                else if (R == 2) fft_passN<2, MAXN, NT, 2>(z, tw, Ns, mg, M, ts, tid);
+                else if (R == 3) fft_passN<3, MAXN, NT, 2>(z, tw, Ns, mg, M, ts, tid);
+                else fft_passN<5, MAXN, NT, 2>(z, tw, Ns, mg, M, ts, tid);
+                Ns *= R;
+            }
+            const float add = pl ? 0.f : dc;
+            for (int i = tid; i < 2 * w; i += NT) {
+                const int q = i >= w, k = i - q * w;
+                if (q >= npair) continue;
+                const float2 zk = z[k * 2 + q], zn = z[(k ? w - k : 0) * 2 + q], post = P.post[k];
+                const float ax = 0.5f * (zk.x + zn.x), ay = 0.5f * (zk.y - zn.y); // as dct_from_fft
+                const float bx = 0.5f * (zk.y + zn.y), by = -0.5f * (zk.x - zn.x);
+                const float y0 = post.x * ax + post.y * ay, y1 = post.x * bx + post.y * by;
+                float *o0 = (pl ? Rb : Ra) + ((int64_t)f * h + r + 2 * q) * w;
+                o0[k] = k ? y0 : y0 + add;
+                o0[w + k] = k ? y1 : y1 + add;
+            }
+        }
+    }
+}
+
+#endif // DCT_ROWS2
 
 // ---- host side ---------------------------------------------------------------------------------------------
 // radix-8 passes first, then 4, 2, 3, 5; false if n is odd, has another prime factor, or is too short / too long to pay
@@ -448,6 +521,12 @@ void launch_dct_full_fft(hipStream_t st, const uint8_t *planes, int pitch, int64
     const dim3 gr((h + rpw - 1) / rpw, n);
     // (NSEQ = 2 - both planes' row pairs through the passes together - measured SLOWER at every size: 1080p 1.52 ms against
     // 1.11, 720p 0.45 against 0.37, 540p 0.22 against 0.20: larger LDS footprint, fewer workgroups per CU)
+#if DCT_ROWS2
+    if (w <= 2048)
+        hipLaunchKernelGGL((k_dct_fft_rows2<2048, 256>), gr, dim3(256), (size_t)2 * w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra,
+                           Rb, rpw, (int)energy, (int)temporal);
+    else
+#endif
     if (w <= 2048)
         hipLaunchKernelGGL((k_dct_fft_rows<1, 2048, 256>), gr, dim3(256), (size_t)w * 8, st, planes, pitch, plane_stride, h, w, pw_, Ra, Rb,
                            rpw, (int)energy, (int)temporal);
