@@ -22,7 +22,8 @@
 //   k_fb_resize<2>: the coarser level's flow upsampled and doubled (once per level)
 //   k_fb_iter     : one flow iteration = bilinear warp of the second expansion by the flow -> 5 products per pixel
 //                   (registers only) -> 15x15 box sums in double, OpenCV's running column sums -> regularised 2x2 solve
-// and k_fb_mag for the mean magnitude.  All of it is stencil work on fp32 planes: HBM / LDS / VALU, no MFMA.
+//                   (the last iteration of the finest level also sums |flow| for the mean magnitude)
+// All of it is stencil work on fp32 planes: HBM / LDS / VALU, no MFMA.
 // The kernels of rounds 2-3 (k_fb_blur_h / k_fb_blur_v / k_fb_resize<1> as three passes: the fallback for a level whose
 // patch exceeds the LDS budget; k_fb_update + k_fb_blur_solve with the products through HBM: lab build only) are kept
 // below next to what replaced them; LAB_NOTES.md L6 has the measurements.
@@ -656,15 +657,19 @@ __device__ __forceinline__ constexpr int fi_row_off(int q)
 }
 
 // SRC = 0: the displacement comes from the level's flow field `fin`; SRC = 2: zero (coarsest level, fin unused).
-template <int SRC>
+// MAG: the last iteration of the finest level also sums |flow| of what it stores (float magnitudes, summed in double: the
+// expression of k_fb_mag) into mag[pair][workgroup] - the separate magnitude pass re-read the whole field for that.
+template <int SRC, bool MAG>
 __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, const float *__restrict__ fin, int h, int w,
-                                                   float *__restrict__ fout, int ncb, int QS)
+                                                   float *__restrict__ fout, int ncb, int QS, double *__restrict__ mag)
 {
     static_assert(SRC == 0 || SRC == 2, "the in-flight upsample of rounds 2-3 (SRC = 1) lives in the lab build's k_fb_update only");
     static_assert(FI_R == 2 || FI_R == 4, "rows per step = lanes per group = adjacent output columns per lane");
     // two buffers, alternating by step: ONE barrier per step (a step's stores go to the buffer read two steps ago, and every
     // thread passed the barrier in between only after finishing those reads; 16 / FI_R steps per loop iteration is even)
     __shared__ __align__(16) unsigned char vsb[2][5 * FI_CHB];
+    __shared__ double mag_red[FI_NT / 64];
+    double macc = 0;
     const int t = threadIdx.x;
     const int cb = blockIdx.x % ncb, sb = blockIdx.x / ncb;
     const int x0 = cb * FI_OUT, ys = sb * QS;
@@ -761,17 +766,26 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
                         const double g11 = sw[j][0] * scale, g12 = sw[j][1] * scale, g22 = sw[j][2] * scale, h1 = sw[j][3] * scale,
                                      h2 = sw[j][4] * scale;
                         const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                        f[2 * j] = (float)((g11 * h2 - g12 * h1) * idet);
-                        f[2 * j + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+                        const float fx = (float)((g11 * h2 - g12 * h1) * idet), fy = (float)((g22 * h1 - g12 * h2) * idet);
+                        f[2 * j] = fx;
+                        f[2 * j + 1] = fy;
+                        if (MAG) macc += (double)sqrtf(fx * fx + fy * fy);
                     }
                 }
             }
         }
     }
+    if (MAG) {
+        const double tot = block_sum(macc, mag_red);
+        if (t == 0) mag[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
 }
 
 // ---- mean magnitude --------------------------------------------------------------------------------
-// grid = (FB_MAG_BLOCKS, pairs); partials[pair][block] then a fixed-order finalize (bit-reproducible)
+// partials[pair][block] (left by the last k_fb_iter; in the lab build's two-kernel form by k_fb_mag), then a fixed-order
+// finalize (bit-reproducible)
+#ifdef VQA_AB_VARIANTS
+// grid = (FB_MAG_BLOCKS, pairs)
 constexpr int FB_MAG_BLOCKS = 64;
 
 __global__ __launch_bounds__(256) void k_fb_mag(const float *__restrict__ flow, int64_t P, double *__restrict__ partials)
@@ -784,14 +798,15 @@ __global__ __launch_bounds__(256) void k_fb_mag(const float *__restrict__ flow, 
     const double t = block_sum(s, red);
     if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * FB_MAG_BLOCKS + blockIdx.x] = t;
 }
+#endif
 
-__global__ void k_fb_mag_finalize(const double *__restrict__ partials, int pairs, double inv_count, int first_valid,
+__global__ void k_fb_mag_finalize(const double *__restrict__ partials, int nblk, int pairs, double inv_count, int first_valid,
                                   vqa_frame_metrics *__restrict__ res)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= pairs) return;
     double s = 0;
-    for (int i = 0; i < FB_MAG_BLOCKS; i++) s += partials[(int64_t)p * FB_MAG_BLOCKS + i];
+    for (int i = 0; i < nblk; i++) s += partials[(int64_t)p * nblk + i];
     res[p].flow_mag_mean = (p == 0 && !first_valid) ? 0.0 : s * inv_count;
 }
 
@@ -892,42 +907,77 @@ void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int 
 #endif
 
 // One fused iteration: flow_out = solve(box15x15(products(R, flow))).  flow == nullptr: zero flow (coarsest level).
+// mag_partials (fb_iter_blocks(..) doubles per pair, or null): also leave the partial sums of |flow_out| there.
 // flow_out must not alias the input: neighbours read it while it is written.  (Upsampling the coarser field inside the
 // first iteration, as rounds 2-3 did in k_fb_update<1>, put eight dependent loads per row on the march's critical path and
 // cost more than writing the upsampled field once with k_fb_resize<2>: LAB_NOTES.md L6.)
-void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *flow_out)
+// workgroups per pair of launch_fb_iter at this geometry (= partials per pair of its magnitude sums)
+static void fb_iter_geometry(int pairs, int h, int w, int &ncb, int &ns, int &QS)
 {
-    const int ncb = (w + FI_OUT - 1) / FI_OUT;
+    ncb = (w + FI_OUT - 1) / FI_OUT;
     // Strips.  A workgroup's march is a chain of dependent steps, so a launch costs (residency rounds) x (rows a workgroup
     // marches): the chip holds 768 of these workgroups at once (3 per CU: 160 VGPRs, 48 KB LDS).  Take the strip count
     // that minimises rounds x (strip rows + 16 priming rows); strips are >= 32 rows.  One strip per frame - when that
     // wins - makes the column sums follow OpenCV's whole-frame order exactly.
-    int ns = 1, QS = (h + 15) / 16 * 16;
-    {
-        const int cap = h / 32 < 1 ? 1 : (h / 32 > 64 ? 64 : h / 32);
-        long long best = -1;
-        for (int n = 1; n <= cap; n++) {
-            const int qs = ((h + n - 1) / n + 15) / 16 * 16, ne = (h + qs - 1) / qs;
-            constexpr int RES = 768 * 256 / FI_NT; // workgroups resident at once (3 waves per SIMD)
-            const long long blocks = (long long)ncb * ne * pairs, cost = ((blocks + RES - 1) / RES) * (qs + 16);
-            if (best < 0 || cost < best) { best = cost; ns = ne; QS = qs; }
-        }
+    ns = 1;
+    QS = (h + 15) / 16 * 16;
+    const int cap = h / 32 < 1 ? 1 : (h / 32 > 64 ? 64 : h / 32);
+    long long best = -1;
+    for (int n = 1; n <= cap; n++) {
+        const int qs = ((h + n - 1) / n + 15) / 16 * 16, ne = (h + qs - 1) / qs;
+        constexpr int RES = 768 * 256 / FI_NT; // workgroups resident at once (3 waves per SIMD)
+        const long long blocks = (long long)ncb * ne * pairs, cost = ((blocks + RES - 1) / RES) * (qs + 16);
+        if (best < 0 || cost < best) { best = cost; ns = ne; QS = qs; }
     }
-    dim3 grid(ncb * ns, pairs);
-    if (flow)
-        hipLaunchKernelGGL(k_fb_iter<0>, grid, dim3(FI_NT), 0, st, R, flow, h, w, flow_out, ncb, QS);
-    else
-        hipLaunchKernelGGL(k_fb_iter<2>, grid, dim3(FI_NT), 0, st, R, nullptr, h, w, flow_out, ncb, QS);
 }
 
+// upper bound of fb_iter_blocks over every pair count (sizes the partials buffer)
+int fb_iter_max_blocks(int h, int w)
+{
+    const int cap = h / 32 < 1 ? 1 : (h / 32 > 64 ? 64 : h / 32);
+    return (w + FI_OUT - 1) / FI_OUT * cap;
+}
+
+int fb_iter_blocks(int pairs, int h, int w)
+{
+    int ncb, ns, QS;
+    fb_iter_geometry(pairs, h, w, ncb, ns, QS);
+    return ncb * ns;
+}
+
+void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *flow_out, double *mag_partials)
+{
+    int ncb, ns, QS;
+    fb_iter_geometry(pairs, h, w, ncb, ns, QS);
+    dim3 grid(ncb * ns, pairs);
+    if (flow && mag_partials)
+        hipLaunchKernelGGL((k_fb_iter<0, true>), grid, dim3(FI_NT), 0, st, R, flow, h, w, flow_out, ncb, QS, mag_partials);
+    else if (flow)
+        hipLaunchKernelGGL((k_fb_iter<0, false>), grid, dim3(FI_NT), 0, st, R, flow, h, w, flow_out, ncb, QS, nullptr);
+    else if (mag_partials)
+        hipLaunchKernelGGL((k_fb_iter<2, true>), grid, dim3(FI_NT), 0, st, R, nullptr, h, w, flow_out, ncb, QS, mag_partials);
+    else
+        hipLaunchKernelGGL((k_fb_iter<2, false>), grid, dim3(FI_NT), 0, st, R, nullptr, h, w, flow_out, ncb, QS, nullptr);
+}
+
+// mean |flow| from the partial sums the last iteration left (nblk = fb_iter_blocks of that launch per pair)
+void launch_fb_mag_finalize(hipStream_t st, const double *partials, int nblk, int pairs, int h, int w, bool first_valid,
+                            vqa_frame_metrics *res)
+{
+    hipLaunchKernelGGL(k_fb_mag_finalize, dim3((pairs + 63) / 64), dim3(64), 0, st, partials, nblk, pairs,
+                       1.0 / ((double)h * (double)w), (int)first_valid, res);
+}
+
+#ifdef VQA_AB_VARIANTS
 int fb_mag_blocks() { return FB_MAG_BLOCKS; }
 
 void launch_fb_mag(hipStream_t st, const float *flow, int pairs, int h, int w, double *partials, bool first_valid,
                    vqa_frame_metrics *res)
 {
     hipLaunchKernelGGL(k_fb_mag, dim3(FB_MAG_BLOCKS, pairs), dim3(256), 0, st, flow, (int64_t)h * w, partials);
-    hipLaunchKernelGGL(k_fb_mag_finalize, dim3((pairs + 63) / 64), dim3(64), 0, st, partials, pairs,
+    hipLaunchKernelGGL(k_fb_mag_finalize, dim3((pairs + 63) / 64), dim3(64), 0, st, partials, FB_MAG_BLOCKS, pairs,
                        1.0 / ((double)h * (double)w), (int)first_valid, res);
 }
+#endif
 
 } // namespace vqa

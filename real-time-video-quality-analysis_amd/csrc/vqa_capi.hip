@@ -455,7 +455,13 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
     if (two_kernel && (rc = ensure(c, c->fb_M, sizeof(float) * 5 * P * mc))) return rc;
     if ((rc = ensure(c, c->fb_flow0, sizeof(float) * 2 * P * mc))) return rc;
     if ((rc = ensure(c, c->fb_flow1, sizeof(float) * 2 * P * mc))) return rc;
-    if ((rc = ensure(c, c->fb_part, sizeof(double) * fb_mag_blocks() * mc))) return rc;
+    {
+        int nb = fb_iter_max_blocks(h, w); // partial |flow| sums per pair: one per workgroup of the last iteration
+#ifdef VQA_AB_VARIANTS
+        if (fb_mag_blocks() > nb) nb = fb_mag_blocks();
+#endif
+        if ((rc = ensure(c, c->fb_part, sizeof(double) * (size_t)nb * mc))) return rc;
+    }
     float *tmp = (float *)c->fb_tmp.p, *blur = (float *)c->fb_blur.p, *img = (float *)c->fb_img.p;
     float *R = (float *)c->fb_R.p;
 #ifdef VQA_AB_VARIANTS
@@ -516,14 +522,21 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
                     in = prev_flow;
                 }
                 for (int i = 0; i < iters; i++) {
-                    launch_fb_iter(st, R, in, pairs, lh, lw, flow);
+                    // the last iteration of the finest level also leaves the partial sums of |flow| (no magnitude pass)
+                    const bool last = k == 0 && i == iters - 1;
+                    launch_fb_iter(st, R, in, pairs, lh, lw, flow, last ? (double *)c->fb_part.p : nullptr);
                     float *t = flow; flow = prev_flow; prev_flow = t;
                     in = prev_flow;
                 }
             }
             pw = lw; ph = lh;
         }
-        launch_fb_mag(st, prev_flow, pairs, h, w, (double *)c->fb_part.p, a > 0 || first_has_prev, res + a);
+#ifdef VQA_AB_VARIANTS
+        if (two_kernel) launch_fb_mag(st, prev_flow, pairs, h, w, (double *)c->fb_part.p, a > 0 || first_has_prev, res + a);
+        else
+#endif
+        launch_fb_mag_finalize(st, (const double *)c->fb_part.p, fb_iter_blocks(pairs, h, w), pairs, h, w, a > 0 || first_has_prev,
+                               res + a);
     }
     return VQA_OK;
 }

@@ -136,16 +136,24 @@ void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, 
 void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out);
 // one flow iteration (products + 15x15 box sums + solve, fused; the products never reach HBM).  flow == nullptr: zero
 // flow (coarsest level); flow_out must not alias the input
-void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *flow_out);
+void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *flow_out,
+                    double *mag_partials = nullptr);
+// workgroups (= magnitude partials) per pair of that launch, and the mean |flow| from them
+int fb_iter_blocks(int pairs, int h, int w);
+int fb_iter_max_blocks(int h, int w); // >= fb_iter_blocks for every pair count
+void launch_fb_mag_finalize(hipStream_t st, const double *partials, int nblk, int pairs, int h, int w, bool first_valid,
+                            vqa_frame_metrics *res);
 #ifdef VQA_AB_VARIANTS // the two-kernel form of rounds 2-3 (VQA_FB_VARIANT=1 in the lab build)
 void launch_fb_update(hipStream_t st, const float *R, const float *flow, int pairs, int h, int w, float *M);
 void launch_fb_update_first(hipStream_t st, const float *R, const float *coarse, int ch, int cw, const fb_resize_tabs &T,
                             float mul, int pairs, int h, int w, float *M);
 void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int w, float *flow);
 #endif
+#ifdef VQA_AB_VARIANTS // the separate magnitude pass of rounds 2-3 (with the two-kernel iteration)
 int fb_mag_blocks();
 void launch_fb_mag(hipStream_t st, const float *flow, int pairs, int h, int w, double *partials, bool first_valid,
                    vqa_frame_metrics *res);
+#endif
 
 // k_quality.hip
 int ssim_gauss_blocks(int h, int w);
