@@ -677,9 +677,9 @@ def main():
                 "k_block_sad": 2 * P * B,
                 # Farneback, per level-0 pixel and pair, every kernel reading its inputs and writing its outputs once:
                 # level image 4 B + expansion 24 B + upsampled flow 10 B + 3 fused iterations x 56 B (R0 20 + R1 20 +
-                # flow in 8 + flow out 8) = 206 B, x 4/3 for the pyramid, + 4 B of u8 reads (one per level) + 8 B for the
-                # magnitude pass = 287 B (rounds 2-3, products through HBM: 440 B)
-                "farneback(pyramid)": 287 * P * B,
+                # flow in 8 + flow out 8) = 206 B, x 4/3 for the pyramid, + 4 B of u8 reads (one per level) = 279 B
+                # (the magnitude is summed by the last iteration; rounds 2-3, products through HBM: 440 B)
+                "farneback(pyramid)": 279 * P * B,
             }
             def _smooth(n):  # the library's rule (k_dct_fft.hip, dct_fft_factor): even, 128..4096, prime factors 2, 3, 5
                 if n < 128 or n > 4000 or n % 2:
