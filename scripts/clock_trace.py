@@ -75,6 +75,9 @@ def main():
     ref, dist = DeviceFrames(rb.ptr, B + 1, h, w, owner=rb), DeviceFrames(db.ptr, B + 1, h, w, owner=db)
     ref_b, dist_b, prev0 = ref.slice(1, B + 1), dist.slice(1, B + 1), dist.frame(0)
     params = eng.make_params(dct_mode=N.DCT_BLOCK8)
+    params_fb = eng.make_params(dct_mode=N.DCT_BLOCK8, motion_mode=N.MOTION_FARNEBACK)
+    params_full = eng.make_params(dct_mode=N.DCT_FULL)
+    dist64 = dist.slice(1, 65)
     planes = bgr_planes(h, w)
 
     def c3():
@@ -92,6 +95,9 @@ def main():
         ("canny only (+gray)", lambda: eng.complexity(dist_b, prev0=prev0, mask=N.M_EDGE, params=params)),
         ("k_dct8 only (+gray)", lambda: eng.complexity(dist_b, prev0=prev0, mask=N.M_DCT | N.M_TEMPORAL_DCT, params=params)),
         ("gray + histograms only", lambda: eng.complexity(dist_b, prev0=prev0, mask=N.M_GRAY_HIST | N.M_COLOR_HIST, params=params)),
+        # the reference-true modes, 64 frames per launch (c3ref's batch)
+        ("farneback pyramid only (+gray), 64 pairs", lambda: eng.complexity(dist64, prev0=prev0, mask=N.M_MOTION, params=params_fb)),
+        ("full-frame DCT only (+gray), 64 frames", lambda: eng.complexity(dist64, prev0=prev0, mask=N.M_DCT | N.M_TEMPORAL_DCT, params=params_full)),
     ]
     th = threading.Thread(target=poll, daemon=True)
     th.start()
