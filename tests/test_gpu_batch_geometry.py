@@ -129,3 +129,27 @@ def test_c3ref_batch_64x1080p_reference_definitions(engine):
             bad[j] = (m, notes)
     pool.shutdown()
     assert not bad, bad
+
+
+def test_farneback_chunk_seam_at_1080p(engine):
+    """The Farneback pyramid works on chunks of at most 12 GiB of scratch (119 pairs of 1080p): a 125-pair batch is two
+    chunks (119 + 6) with different strip geometries, partial-sum counts and a halo plane at the seam.  Oracle at both
+    sides of the seam and at both ends; every pair positive."""
+    from rtvqa_amd import _native as N
+    h, w, B, positions = 1080, 1920, 125, [0, 118, 119, 124]
+    keep = sorted(set(positions) | set(j + 1 for j in positions))
+    ref_all, dist_all, host = _resident_stream(engine, h, w, B, keep)
+    del ref_all
+    dist_b, prev0 = dist_all.slice(1, B + 1), dist_all.frame(0)
+
+    def exp(j):
+        from oracle import c_oracle as co
+        return j, co.farneback(co.bgr2gray(host[j][1]), co.bgr2gray(host[j + 1][1]))
+    pool = ThreadPoolExecutor(4)
+    fut = pool.map(exp, positions)
+    c = engine.complexity(dist_b, prev0=prev0, mask=N.M_MOTION, motion_mode=N.MOTION_FARNEBACK)
+    assert c.shape == (B,) and (c["flow_mag_mean"] > 0).all() and (c["has_prev"] == 1).all()
+    for j, want in fut:
+        got = float(c[j]["flow_mag_mean"])
+        assert abs(got - want) <= check.RTOL * want, (j, got, want)
+    pool.shutdown()
