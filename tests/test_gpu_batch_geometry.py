@@ -153,3 +153,25 @@ def test_farneback_chunk_seam_at_1080p(engine):
         got = float(c[j]["flow_mag_mean"])
         assert abs(got - want) <= check.RTOL * want, (j, got, want)
     pool.shutdown()
+
+
+def test_farneback_2160p_against_the_oracle(engine):
+    """The reference-true motion metric at 2160p (BASELINE configs[3]'s geometry): 16 column blocks per pair, five pyramid
+    levels' worth of tile shapes in the level kernel; three pairs, oracle on the first and the last."""
+    from rtvqa_amd import _native as N
+    h, w, B, positions = 2160, 3840, 3, [0, 2]
+    keep = sorted(set(positions) | set(j + 1 for j in positions))
+    ref_all, dist_all, host = _resident_stream(engine, h, w, B, keep)
+    del ref_all
+    dist_b, prev0 = dist_all.slice(1, B + 1), dist_all.frame(0)
+
+    def exp(j):
+        from oracle import c_oracle as co
+        return j, co.farneback(co.bgr2gray(host[j][1]), co.bgr2gray(host[j + 1][1]))
+    pool = ThreadPoolExecutor(2)
+    fut = pool.map(exp, positions)
+    c = engine.complexity(dist_b, prev0=prev0, mask=N.M_MOTION, motion_mode=N.MOTION_FARNEBACK)
+    for j, want in fut:
+        got = float(c[j]["flow_mag_mean"])
+        assert abs(got - want) <= check.RTOL * want, (j, got, want)
+    pool.shutdown()
