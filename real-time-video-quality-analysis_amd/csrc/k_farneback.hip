@@ -18,7 +18,7 @@
 // Structure per pyramid level (coarse to fine), for a chunk of frame pairs whose planes stay resident (round 4):
 //   k_fb_level    : float(gray) -> separable Gaussian (BORDER_REFLECT_101) -> INTER_LINEAR resize to the level  (per plane,
 //                   (2x2 mean when exactly halving), ONE kernel, only the samples the level reads                  shared by
-//   k_fb_polyexp  : 11x11 polynomial expansion -> 5 coefficient PLANES per gray plane                              both pairs)
+//   k_fb_polyexp_march: 11x11 polynomial expansion -> 5 coefficient PLANES per gray plane                          both pairs)
 //   k_fb_resize<2>: the coarser level's flow upsampled and doubled (once per level)
 //   k_fb_iter     : one flow iteration = bilinear warp of the second expansion by the flow -> 5 products per pixel
 //                   (registers only) -> 15x15 box sums in double, OpenCV's running column sums -> regularised 2x2 solve
@@ -419,6 +419,85 @@ __global__ __launch_bounds__(256) void k_fb_polyexp(const float *__restrict__ in
             d[3 * P] = (float)(b1 * C.ig03 + b4 * C.ig33);
             d[2 * P] = (float)(b1 * C.ig03 + b5 * C.ig33);
             d[4 * P] = (float)(b6 * C.ig55);
+        }
+    }
+}
+
+// ---- polynomial expansion, marching form (round 4) ---------------------------------------------------------------
+// The tile kernel above re-reads 26 rows per 16 (and clamps 11 addresses per LDS entry); here a workgroup owns PM_NT
+// columns (PM_OUT = PM_NT - 10 outputs + the 5-column replicated halo either side) of a row strip and marches down it:
+// thread = column, the 11 rows of its vertical taps sit in a register ring (ONE load per row and thread), the three
+// vertical sums of a row go through LDS (double-buffered: one barrier per row), the horizontal pass and the 6x6 solve
+// are the tile kernel's expressions in the same order, so the coefficient planes are bit-identical to its.
+// grid = (ncb * ns, planes), block = PM_NT; QS = rows per strip
+#ifndef FB_POLY_MARCH
+#define FB_POLY_MARCH 1 // 1 = shipped; 0 = measurement build (the tile kernel)
+#endif
+constexpr int PM_NT = 256, PM_OUT = PM_NT - 2 * PE_N;
+
+__global__ __launch_bounds__(PM_NT) void k_fb_polyexp_march(const float *__restrict__ in, int h, int w, fb_poly C,
+                                                            float *__restrict__ out, int ncb, int QS)
+{
+    __shared__ float rowb[2][3][PM_NT]; // (one float4 per column - a 16-byte LDS access per tap instead of three - measured no faster)
+    const int t = threadIdx.x;
+    const int cb = blockIdx.x % ncb, sb = blockIdx.x / ncb;
+    const int x0 = cb * PM_OUT, ys = sb * QS, yend = min(ys + QS, h);
+    const int xx = min(max(x0 - PE_N + t, 0), w - 1); // the horizontal pass replicates the border triples
+    const float *col = in + (int64_t)blockIdx.z * h * w + xx;
+    const float *g = C.g + PE_N, *xg = C.xg + PE_N, *xxg = C.xxg + PE_N;
+    const int64_t P = (int64_t)h * w;
+    const int xo = x0 + t - PE_N;                      // this thread's output column (when 5 <= t < PM_NT - 5)
+    const bool writer = t >= PE_N && t < PM_NT - PE_N && xo < w;
+    float *dcol = out + (int64_t)blockIdx.z * P * 5 + xo;
+    auto ld = [&](int y) { return col[(int64_t)min(max(y, 0), h - 1) * w]; };
+    // ring slot of row y: (y - (ys - 5)) mod 11; the march below is unrolled by 11 so that the slots are static
+    float win[11];
+#pragma unroll
+    for (int k = 0; k < 10; k++) win[k] = ld(ys - PE_N + k);  // rows ys-5 .. ys+4
+    float nxt = ld(ys + PE_N);                                 // row ys+5, the entering row of output row ys
+    int n = 0;
+    for (int base = 0; ys + base < yend; base += 11) {
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const int y = ys + base + i;
+            if (y < yend) { // wave-uniform
+                win[(i + 10) % 11] = nxt;       // row y + 5
+                nxt = ld(y + PE_N + 1);         // one row ahead of its use
+                // vertical pass: the tile kernel's expressions (a = row y - k, b = row y + k, both clamped by ld)
+                const float c0 = win[(i + 5) % 11];
+                float t0 = c0 * g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int k = 1; k <= PE_N; k++) {
+                    const float a = win[(i + 5 - k) % 11], b = win[(i + 5 + k) % 11];
+                    const float p = a + b;
+                    t0 = t0 + g[k] * p;
+                    t1 = t1 + xg[k] * (b - a);
+                    t2 = t2 + xxg[k] * p;
+                }
+                float(*rb)[PM_NT] = rowb[n & 1];
+                rb[0][t] = t0; rb[1][t] = t1; rb[2][t] = t2;
+                __syncthreads();
+                if (writer) {
+                    double b1 = rb[0][t] * g[0], b2 = 0, b3 = rb[1][t] * g[0], b4 = 0, b5 = rb[2][t] * g[0], b6 = 0;
+#pragma unroll
+                    for (int k = 1; k <= PE_N; k++) {
+                        const double tg = rb[0][t + k] + rb[0][t - k];
+                        b1 += tg * g[k];
+                        b4 += tg * xxg[k];
+                        b2 += (rb[0][t + k] - rb[0][t - k]) * xg[k];
+                        b3 += (rb[1][t + k] + rb[1][t - k]) * g[k];
+                        b6 += (rb[1][t + k] - rb[1][t - k]) * xg[k];
+                        b5 += (rb[2][t + k] + rb[2][t - k]) * g[k];
+                    }
+                    float *d = dcol + (int64_t)y * w;
+                    d[P] = (float)(b2 * C.ig11);
+                    d[0] = (float)(b3 * C.ig11);
+                    d[3 * P] = (float)(b1 * C.ig03 + b4 * C.ig33);
+                    d[2 * P] = (float)(b1 * C.ig03 + b5 * C.ig33);
+                    d[4 * P] = (float)(b6 * C.ig55);
+                }
+                n++;
+            }
         }
     }
 }
@@ -875,6 +954,19 @@ void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, 
 
 void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out)
 {
+#if FB_POLY_MARCH
+    {
+        // strips so that a launch has ~8 workgroups per CU (the kernel's occupancy), at least 32 rows each
+        const int ncb = (w + PM_OUT - 1) / PM_OUT;
+        int ns = (int)((2048 + (long long)ncb * planes - 1) / ((long long)ncb * planes));
+        const int cap = h / 32 < 1 ? 1 : h / 32;
+        ns = ns < 1 ? 1 : (ns > cap ? cap : ns);
+        const int QS = (h + ns - 1) / ns;
+        ns = (h + QS - 1) / QS;
+        hipLaunchKernelGGL(k_fb_polyexp_march, dim3(ncb * ns, 1, planes), dim3(PM_NT), 0, st, in, h, w, C, out, ncb, QS);
+        return;
+    }
+#endif
     dim3 grid((w + PE_TX - 1) / PE_TX, (h + PE_TY * PE_TILES - 1) / (PE_TY * PE_TILES), planes);
     hipLaunchKernelGGL(k_fb_polyexp, grid, dim3(256), 0, st, in, h, w, C, out);
 }
