@@ -355,10 +355,16 @@ __global__ __launch_bounds__(256) void k_fb_level(fb_level_args A, fb_taps T)
     }
 }
 
+#ifndef FB_POLY_MARCH
+#define FB_POLY_MARCH 1 // 1 = shipped: k_fb_polyexp_march; 0 = measurement build: the tile kernel of rounds 1-3
+#endif
+constexpr int PE_N = 5;
+
+#if !FB_POLY_MARCH
 // ---- polynomial expansion (FarnebackPolyExp, n = 5) ------------------------------------------------
 // Tile of PE_TY rows x PE_TX columns per workgroup: the vertical pass (float) fills LDS for the tile's
 // columns plus a 5-column replicated halo, the horizontal pass (double accumulators) reads it back.
-constexpr int PE_TX = 64, PE_TY = 16, PE_N = 5;   // 16 rows per tile: the vertical pass re-reads 26 rows per 16 (4-row tiles: 14 per 4)
+constexpr int PE_TX = 64, PE_TY = 16;   // 16 rows per tile: the vertical pass re-reads 26 rows per 16 (4-row tiles: 14 per 4)
 constexpr int PE_TILES = 2; // consecutive row tiles per workgroup
 
 // grid = (ceil(w/PE_TX), ceil(h/(PE_TY * PE_TILES)), planes), block = 256
@@ -423,6 +429,9 @@ __global__ __launch_bounds__(256) void k_fb_polyexp(const float *__restrict__ in
     }
 }
 
+#endif // !FB_POLY_MARCH
+
+#if FB_POLY_MARCH
 // ---- polynomial expansion, marching form (round 4) ---------------------------------------------------------------
 // The tile kernel above re-reads 26 rows per 16 (and clamps 11 addresses per LDS entry); here a workgroup owns PM_NT
 // columns (PM_OUT = PM_NT - 10 outputs + the 5-column replicated halo either side) of a row strip and marches down it:
@@ -430,9 +439,6 @@ __global__ __launch_bounds__(256) void k_fb_polyexp(const float *__restrict__ in
 // vertical sums of a row go through LDS (double-buffered: one barrier per row), the horizontal pass and the 6x6 solve
 // are the tile kernel's expressions in the same order, so the coefficient planes are bit-identical to its.
 // grid = (ncb * ns, planes), block = PM_NT; QS = rows per strip
-#ifndef FB_POLY_MARCH
-#define FB_POLY_MARCH 1 // 1 = shipped; 0 = measurement build (the tile kernel)
-#endif
 constexpr int PM_NT = 256, PM_OUT = PM_NT - 2 * PE_N;
 
 __global__ __launch_bounds__(PM_NT) void k_fb_polyexp_march(const float *__restrict__ in, int h, int w, fb_poly C,
@@ -501,6 +507,8 @@ __global__ __launch_bounds__(PM_NT) void k_fb_polyexp_march(const float *__restr
         }
     }
 }
+
+#endif // FB_POLY_MARCH
 
 // ---- FarnebackUpdateMatrices: pair p uses expansions of planes p and p + 1 -------------------------
 // SRC: where the flow comes from.  0 = the level's flow field; 1 = the coarser level's flow, resized
@@ -955,20 +963,18 @@ void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, 
 void launch_fb_polyexp(hipStream_t st, const float *in, int planes, int h, int w, const fb_poly &C, float *out)
 {
 #if FB_POLY_MARCH
-    {
-        // strips so that a launch has ~8 workgroups per CU (the kernel's occupancy), at least 32 rows each
-        const int ncb = (w + PM_OUT - 1) / PM_OUT;
-        int ns = (int)((2048 + (long long)ncb * planes - 1) / ((long long)ncb * planes));
-        const int cap = h / 32 < 1 ? 1 : h / 32;
-        ns = ns < 1 ? 1 : (ns > cap ? cap : ns);
-        const int QS = (h + ns - 1) / ns;
-        ns = (h + QS - 1) / QS;
-        hipLaunchKernelGGL(k_fb_polyexp_march, dim3(ncb * ns, 1, planes), dim3(PM_NT), 0, st, in, h, w, C, out, ncb, QS);
-        return;
-    }
-#endif
+    // strips so that a launch has ~8 workgroups per CU, at least 32 rows each
+    const int ncb = (w + PM_OUT - 1) / PM_OUT;
+    int ns = (int)((2048 + (long long)ncb * planes - 1) / ((long long)ncb * planes));
+    const int cap = h / 32 < 1 ? 1 : h / 32;
+    ns = ns < 1 ? 1 : (ns > cap ? cap : ns);
+    const int QS = (h + ns - 1) / ns;
+    ns = (h + QS - 1) / QS;
+    hipLaunchKernelGGL(k_fb_polyexp_march, dim3(ncb * ns, 1, planes), dim3(PM_NT), 0, st, in, h, w, C, out, ncb, QS);
+#else
     dim3 grid((w + PE_TX - 1) / PE_TX, (h + PE_TY * PE_TILES - 1) / (PE_TY * PE_TILES), planes);
     hipLaunchKernelGGL(k_fb_polyexp, grid, dim3(256), 0, st, in, h, w, C, out);
+#endif
 }
 
 #ifdef VQA_AB_VARIANTS
