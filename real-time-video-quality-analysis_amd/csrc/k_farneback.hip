@@ -16,7 +16,7 @@
 // 1e-16 level only.)
 //
 // Structure per pyramid level (coarse to fine), for a chunk of frame pairs whose planes stay resident (round 4):
-//   k_fb_level    : float(gray) -> separable Gaussian (BORDER_REFLECT_101) -> INTER_LINEAR resize to the level  (per plane,
+//   k_fb_level3 / k_fb_level: float(gray) -> separable Gaussian (BORDER_REFLECT_101) -> resize to the level    (per plane,
 //                   (2x2 mean when exactly halving), ONE kernel, only the samples the level reads                  shared by
 //   k_fb_polyexp_march: 11x11 polynomial expansion -> 5 coefficient PLANES per gray plane                          both pairs)
 //   k_fb_resize<2>: the coarser level's flow upsampled and doubled (once per level)
@@ -909,12 +909,102 @@ void launch_fb_blur(hipStream_t st, const uint8_t *gray, int pitch, int64_t plan
                        nc, rows, nr, out);
 }
 
+// ---- the level image of the two finest levels: 3-tap blur (+ exact halving), marching ----------------------------
+// ksize 3 covers the finest level (no resize, S = 1) and the first halving (sigma 0.5, INTER_AREA's 2x2 mean, S = 2) of
+// a 0.5 pyramid - 15/16 of the pyramid's pixels.  thread = one level column marching down a row strip: the horizontal
+// pass of the entering source row(s) straight from the u8 plane (3 or 4 byte loads, L1), the previous ones in
+// registers, no LDS, no barrier.  The expressions are k_fb_blur_h / k_fb_blur_v / k_fb_resize<1> (mode 1)'s, in order.
+// grid = (ceil(lw / 256), ns, planes), block = 256; QS = level rows per strip
+template <int S>
+__global__ __launch_bounds__(256) void k_fb_level3(const uint8_t *__restrict__ gray, int pitch, int64_t plane_stride, int h, int w,
+                                                   float k1, float k2, float *__restrict__ out, int lh, int lw, int QS)
+{
+    const int X = blockIdx.x * 256 + threadIdx.x;
+    if (X >= lw) return;
+    const uint8_t *plane = gray + (int64_t)blockIdx.z * plane_stride;
+    float *o = out + (int64_t)blockIdx.z * lh * lw + X;
+    const int Y0 = blockIdx.y * QS, Y1 = min(Y0 + QS, lh);
+    if (S == 1) {
+        const int xl = fb_reflect101(X - 1, w), xr = fb_reflect101(X + 1, w);
+        auto hb = [&](int y) {
+            const uint8_t *row = plane + (int64_t)fb_reflect101(y, h) * pitch;
+            float a = (float)row[X] * k1;
+            a += ((float)row[xl] + (float)row[xr]) * k2;
+            return a;
+        };
+        float hm = hb(Y0 - 1), h0 = hb(Y0);
+        for (int y = Y0; y < Y1; y += 4) { // four rows in flight
+            float hn[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) hn[u] = hb(min(y + u, Y1 - 1) + 1);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (y + u < Y1) {
+                    float b = h0 * k1;
+                    b += (hm + hn[u]) * k2;
+                    o[(int64_t)(y + u) * lw] = b;
+                    hm = h0;
+                    h0 = hn[u];
+                }
+            }
+        }
+    } else {
+        // source columns 2X, 2X + 1 (w = 2 lw exactly) and their reflected neighbours
+        const int c0 = 2 * X, c1 = 2 * X + 1, cl = fb_reflect101(c0 - 1, w), cr = fb_reflect101(c1 + 1, w);
+        auto hb2 = [&](int y, float &a0, float &a1) {
+            const uint8_t *row = plane + (int64_t)fb_reflect101(y, h) * pitch;
+            const float pl = (float)row[cl], p0 = (float)row[c0], p1 = (float)row[c1], pr = (float)row[cr];
+            a0 = p0 * k1;
+            a0 += (pl + p1) * k2;
+            a1 = p1 * k1;
+            a1 += (p0 + pr) * k2;
+        };
+        float am0, am1, a00, a01; // source rows 2Y - 1 and 2Y of the current level row
+        hb2(2 * Y0 - 1, am0, am1);
+        hb2(2 * Y0, a00, a01);
+        for (int Y = Y0; Y < Y1; Y += 2) { // two level rows = four source rows in flight
+            float n0[4], n1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) hb2(2 * Y + 1 + u, n0[u], n1[u]);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (Y + u < Y1) {
+                    // blurred rows 2(Y+u), 2(Y+u)+1 at the two columns; the 2x2 mean in k_fb_resize's order
+                    const float p0 = n0[2 * u], p1 = n1[2 * u], q0 = n0[2 * u + 1], q1 = n1[2 * u + 1];
+                    float b00 = a00 * k1; b00 += (am0 + p0) * k2;
+                    float b01 = a01 * k1; b01 += (am1 + p1) * k2;
+                    float b10 = p0 * k1;  b10 += (a00 + q0) * k2;
+                    float b11 = p1 * k1;  b11 += (a01 + q1) * k2;
+                    o[(int64_t)(Y + u) * lw] = (b00 + b01 + b10 + b11) * 0.25f;
+                    am0 = p0; am1 = p1; a00 = q0; a01 = q1;
+                }
+            }
+        }
+    }
+}
+
 // The level image of every plane in one launch (see k_fb_level).  T == nullptr: the finest level (lh x lw = h x w, no
 // resize).  Returns false when the level's patch does not fit the LDS budget (caller falls back to the three-kernel path).
 bool launch_fb_level(hipStream_t st, const uint8_t *gray, int pitch, int64_t plane_stride, int planes, int h, int w,
                      const fb_taps &K, const fb_resize_tabs *T, float *out, int lh, int lw)
 {
     const int r = K.ksize >> 1;
+    if (K.ksize == 3 && (!T || (T->mode == 1 && w == 2 * lw && h == 2 * lh))) {
+        // strips of >= 32 level rows, ~4096 workgroups per launch (the kernel holds 8 per CU and each is a short chain)
+        const int nbx = (lw + 255) / 256;
+        int ns = (int)((4096 + (long long)nbx * planes - 1) / ((long long)nbx * planes));
+        const int cap = lh / 32 < 1 ? 1 : lh / 32;
+        ns = ns < 1 ? 1 : (ns > cap ? cap : ns);
+        int QS = (lh + ns - 1) / ns;
+        QS = (QS + 3) & ~3; // whole batches of rows in flight
+        ns = (lh + QS - 1) / QS;
+        const dim3 grid(nbx, ns, planes);
+        if (!T)
+            hipLaunchKernelGGL(k_fb_level3<1>, grid, dim3(256), 0, st, gray, pitch, plane_stride, h, w, K.k[1], K.k[2], out, lh, lw, QS);
+        else
+            hipLaunchKernelGGL(k_fb_level3<2>, grid, dim3(256), 0, st, gray, pitch, plane_stride, h, w, K.k[1], K.k[2], out, lh, lw, QS);
+        return true;
+    }
     fb_level_args A;
     A.gray = gray; A.pitch = pitch; A.plane_stride = plane_stride; A.h = h; A.w = w;
     A.out = out; A.lh = lh; A.lw = lw;
