@@ -19,7 +19,7 @@
 //   k_fb_level3 / k_fb_level: float(gray) -> separable Gaussian (BORDER_REFLECT_101) -> resize to the level    (per plane,
 //                   (2x2 mean when exactly halving), ONE kernel, only the samples the level reads                  shared by
 //   k_fb_polyexp_march: 11x11 polynomial expansion -> 5 coefficient PLANES per gray plane                          both pairs)
-//   k_fb_resize<2>: the coarser level's flow upsampled and doubled (once per level)
+//   k_fb_upflow   : the coarser level's flow upsampled and doubled (once per level; source patch through LDS)
 //   k_fb_iter     : one flow iteration = bilinear warp of the second expansion by the flow -> 5 products per pixel
 //                   (registers only) -> 15x15 box sums in double, OpenCV's running column sums -> regularised 2x2 solve
 //                   (the last iteration of the finest level also sums |flow| for the mean magnitude)
@@ -207,6 +207,54 @@ __global__ __launch_bounds__(256) void k_fb_resize(const float *__restrict__ src
             if (apply_mul) v *= mul;
             d[c] = v;
         }
+    }
+}
+
+// ---- flow upsample (cv2.resize INTER_LINEAR of a 2-channel field to a LARGER size, times mul) ---------------------
+// k_fb_resize<2> gathers four float2 corners per output pixel from global memory: at 2x that is 16 loads for every 2 x 2
+// output quad that shares 3 x 3 source pixels, and the texture path was its limit (0.28 ms per 32 fields of 1080p).  Here a
+// workgroup stages the source patch of its 256 x 8 output tile in LDS with coalesced loads (upscale: at most 257 x 9
+// source pixels) and the corners come from there.  Same tables, same expressions, same order as k_fb_resize<2>.
+// grid = (ceil(dw / 256), ceil(dh / 8), fields), block = 256; requires dw >= sw and dh >= sh
+constexpr int UF_ROWS = 8;
+
+__global__ __launch_bounds__(256) void k_fb_upflow(const float *__restrict__ src, int sh, int sw, float *__restrict__ dst, int dh,
+                                                   int dw, const int32_t *__restrict__ xofs, const float *__restrict__ xa,
+                                                   const int32_t *__restrict__ yofs, const float *__restrict__ yb, float mul)
+{
+    __shared__ float2 tile[UF_ROWS + 1][257];
+    const int t = threadIdx.x, X = blockIdx.x * 256 + t;
+    const int Y0 = blockIdx.y * UF_ROWS, Y1 = min(Y0 + UF_ROWS, dh);
+    const float2 *s2 = reinterpret_cast<const float2 *>(src) + (int64_t)blockIdx.z * sh * sw;
+    // the tables are non-decreasing: the tile's patch is [first column's x0 .. last column's x1] x [first row's y0 .. last row's y1]
+    const int Xl = min(blockIdx.x * 256 + 255, dw - 1);
+    const int xlo = xofs[blockIdx.x * 256], xhi = min(xofs[Xl] + 1, sw - 1);
+    const int ylo = min(max(yofs[Y0], 0), sh - 1), yhi = min(max(yofs[Y1 - 1] + 1, 0), sh - 1);
+    const int ncols = xhi - xlo + 1, nrows = yhi - ylo + 1; // <= 257, <= UF_ROWS + 1 for an upscale
+    for (int r = 0; r < nrows; r++)
+        for (int c = t; c < ncols; c += 256) tile[r][c] = s2[(int64_t)(ylo + r) * sw + xlo + c];
+    __syncthreads();
+    if (X >= dw) return;
+    const int x0 = xofs[X] - xlo, x1 = min(xofs[X] + 1, sw - 1) - xlo;
+    const float a0 = xa[2 * X], a1 = xa[2 * X + 1];
+    float2 *d2 = reinterpret_cast<float2 *>(dst) + (int64_t)blockIdx.z * dh * dw + X;
+#pragma unroll 4
+    for (int y = Y0; y < Y1; y++) {
+        const int y0 = min(max(yofs[y], 0), sh - 1) - ylo, y1 = min(max(yofs[y] + 1, 0), sh - 1) - ylo;
+        const float b0 = yb[2 * y], b1 = yb[2 * y + 1];
+        const float2 p00 = tile[y0][x0], p01 = tile[y0][x1], p10 = tile[y1][x0], p11 = tile[y1][x1];
+        float2 v;
+        {
+            const float r0 = p00.x * a0 + p01.x * a1, r1 = p10.x * a0 + p11.x * a1;
+            v.x = r0 * b0 + r1 * b1;
+        }
+        {
+            const float r0 = p00.y * a0 + p01.y * a1, r1 = p10.y * a0 + p11.y * a1;
+            v.y = r0 * b0 + r1 * b1;
+        }
+        v.x *= mul;
+        v.y *= mul;
+        d2[(int64_t)y * dw] = v;
     }
 }
 
@@ -1041,6 +1089,11 @@ bool launch_fb_level(hipStream_t st, const uint8_t *gray, int pitch, int64_t pla
 void launch_fb_resize(hipStream_t st, const float *src, int sh, int sw, int cn, float *dst, int dh, int dw, int images,
                       const fb_resize_tabs &T, float mul, bool apply_mul)
 {
+    if (cn == 2 && T.mode == 0 && apply_mul && dw >= sw && dh >= sh) { // the pyramid's flow upsample
+        hipLaunchKernelGGL(k_fb_upflow, dim3((dw + 255) / 256, (dh + UF_ROWS - 1) / UF_ROWS, images), dim3(256), 0, st, src, sh, sw, dst,
+                           dh, dw, T.xofs, T.xa, T.yofs, T.yb, mul);
+        return;
+    }
     dim3 grid((dw + 255) / 256, (dh + FB_RB - 1) / FB_RB, images);
     if (cn == 1)
         hipLaunchKernelGGL(k_fb_resize<1>, grid, dim3(256), 0, st, src, sh, sw, dst, dh, dw, T.xofs, T.xa, T.yofs, T.yb,
