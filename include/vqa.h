@@ -165,10 +165,11 @@ VQA_API int vqa_build_flavour(void);
 
 /* ---- per-ctx options (none of them changes a result) ------------------------ */
 enum vqa_option {
-    VQA_OPT_OVERLAP = 0,    /* 1 (default; initial value from VQA_OVERLAP if set): inside one complexity submit block-SAD
-                               and the Canny chain run on two side streams of the ctx next to DCT / ORB and join before
-                               the results are copied (+3 % on the full suite).  0: every kernel on the ctx stream in
-                               program order - per-kernel event times (vqa_profile_*) are then free of overlap          */
+    VQA_OPT_OVERLAP = 0,    /* 1 (default; initial value from VQA_OVERLAP if set): inside one complexity submit block-SAD,
+                               the Canny chain and (VQA_DCT_FULL) the full-frame DCT run on side streams of the ctx next to
+                               the 8x8 DCT / ORB / Farneback kernels and join before the results are copied (+3 % on the
+                               full suite, +5 % with the reference's own definitions).  0: every kernel on the ctx stream
+                               in program order - per-kernel event times (vqa_profile_*) are then free of overlap        */
     VQA_OPT_HYST_STATS = 1  /* 1: fill vqa_frame_metrics.hyst_steps (default 0)                                        */
 };
 /* VQA_ERR_STATE while a submit is pending on the ctx */

@@ -38,8 +38,8 @@ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 struct vqa_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipStream_t side[2] = {nullptr, nullptr};   // VQA_OPT_OVERLAP: block-SAD and the Canny chain on their own streams
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // VQA_OPT_OVERLAP: block-SAD, the Canny chain and the full-frame DCT on their own streams
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::string last_err;
     // options (vqa_set_option)
     bool opt_overlap = true, opt_hyst_stats = false;
@@ -137,11 +137,11 @@ void prof_discard(vqa_ctx *c)
         }                                                                                                  \
     } while (0)
 
-// every stream this ctx may have work on (the main one and, once created, the two side streams of VQA_OPT_OVERLAP)
+// every stream this ctx may have work on (the main one and, once created, the three side streams of VQA_OPT_OVERLAP)
 static int sync_all(vqa_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 3; i++)
         if (c->side[i]) HIPCHK(c, hipStreamSynchronize(c->side[i]));
     return VQA_OK;
 }
@@ -662,7 +662,7 @@ int vqa_destroy(vqa_ctx *c)
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->res_host) (void)hipHostFree(c->res_host);
     if (c->qres_host) (void)hipHostFree(c->qres_host);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
@@ -868,10 +868,33 @@ static int complexity_submit_body(vqa_ctx *c, const uint8_t *frames, const uint8
         pB = gfull + full_stride;  // batch frames only
     }
 
+    // ---- VQA_OPT_OVERLAP (default on): block-SAD, the Canny chain, the DCT metrics and ORB only share the gray planes as
+    // input, so they run side by side: SAD, Canny and the full-frame DCT (the long one of the two DCT forms) fork onto their
+    // own streams here - the planes exist in stream order - and join before the results are copied (QSAD-bound,
+    // scalar-bound and latency-bound kernels next to each other: +3 % on the full suite; the full-frame DCT beside the
+    // Farneback pyramid: c3ref +9 %, LAB_NOTES.md)
+    int dct_mode_eff = P.dct_mode;
+    if (dct_mode_eff == VQA_DCT_AUTO) dct_mode_eff = ((int64_t)ph * pw <= 128 * 128) ? VQA_DCT_FULL : VQA_DCT_BLOCK8;
+    const bool use_side[3] = {c->opt_overlap && want_m && P.motion_mode == VQA_MOTION_SAD, c->opt_overlap && want_e,
+                              c->opt_overlap && (want_dct || want_t) && dct_mode_eff == VQA_DCT_FULL && (want_m || want_e)};
+    const bool overlap = use_side[0] || use_side[1] || use_side[2];
+    hipStream_t st_sad = st, st_canny = st, st_dct = st;
+    if (overlap) {
+        for (int i = 0; i < 3; i++) {
+            if (!use_side[i]) continue;
+            if (!c->side[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+            if (!c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+        }
+        if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        if (use_side[0]) { st_sad = c->side[0]; HIPCHK(c, hipStreamWaitEvent(st_sad, c->ev_fork, 0)); }
+        if (use_side[1]) { st_canny = c->side[1]; HIPCHK(c, hipStreamWaitEvent(st_canny, c->ev_fork, 0)); }
+        if (use_side[2]) { st_dct = c->side[2]; HIPCHK(c, hipStreamWaitEvent(st_dct, c->ev_fork, 0)); }
+    }
+
     // ---- DCT energy / temporal DCT (input: plane A)
     if (want_dct || want_t) {
-        int mode = P.dct_mode;
-        if (mode == VQA_DCT_AUTO) mode = ((int64_t)ph * pw <= 128 * 128) ? VQA_DCT_FULL : VQA_DCT_BLOCK8;
+        const int mode = dct_mode_eff;
         if (mode == VQA_DCT_BLOCK8) {
             const int pb = dct8_blocks_per_frame(ph, pw);
             rc = ensure(c, c->partials, sizeof(double) * 2 * (size_t)pb * n);
@@ -893,8 +916,8 @@ static int complexity_submit_body(vqa_ctx *c, const uint8_t *frames, const uint8
                 if (rc) return rc;
                 rc = ensure(c, c->dct_pt, sizeof(double) * tiles * n);
                 if (rc) return rc;
-                prof_scope ps_(c, VQA_K_DCT_FULL);
-                launch_dct_full_fft(st, pA, pp, plane_stride, n, ph, pw, Pw, Ph, (float *)c->dct_scratch.p, (double *)c->dct_pe.p,
+                prof_scope ps_(c, VQA_K_DCT_FULL, st_dct);
+                launch_dct_full_fft(st_dct, pA, pp, plane_stride, n, ph, pw, Pw, Ph, (float *)c->dct_scratch.p, (double *)c->dct_pe.p,
                                     (double *)c->dct_pt.p, want_dct, want_t, has_prev0, res);
             } else {
                 float *cw = nullptr, *ch = nullptr;
@@ -909,29 +932,13 @@ static int complexity_submit_body(vqa_ctx *c, const uint8_t *frames, const uint8
                 if (rc) return rc;
                 rc = ensure(c, c->dct_pt, sizeof(double) * tiles * n);
                 if (rc) return rc;
-                prof_scope ps_(c, VQA_K_DCT_FULL);
-                launch_dct_full(st, pA, pp, plane_stride, n, ph, pw, cw, ch, (float *)c->dct_scratch.p,
+                prof_scope ps_(c, VQA_K_DCT_FULL, st_dct);
+                launch_dct_full(st_dct, pA, pp, plane_stride, n, ph, pw, cw, ch, (float *)c->dct_scratch.p,
                                 (double *)c->dct_pe.p, (double *)c->dct_pt.p, want_dct, want_t, has_prev0, res);
             }
         }
     }
 
-    // ---- VQA_OPT_OVERLAP (default on): block-SAD, the Canny chain and DCT/ORB only share the gray planes as input, so
-    // they run side by side: SAD and Canny fork onto their own streams here and join before the results are copied
-    // (QSAD-bound, scalar-bound and latency-bound kernels next to each other: +3 % on the full suite, LAB_NOTES.md)
-    const bool overlap = c->opt_overlap && ((want_m && P.motion_mode == VQA_MOTION_SAD) || want_e);
-    hipStream_t st_sad = st, st_canny = st;
-    if (overlap) {
-        for (int i = 0; i < 2; i++) {
-            if (!c->side[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-            if (!c->ev_join[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-        }
-        if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        st_sad = c->side[0]; st_canny = c->side[1];
-        HIPCHK(c, hipEventRecord(c->ev_fork, st));
-        HIPCHK(c, hipStreamWaitEvent(st_sad, c->ev_fork, 0));
-        HIPCHK(c, hipStreamWaitEvent(st_canny, c->ev_fork, 0));
-    }
     // ---- motion on the full-resolution gray planes (the reference never resizes for it, :327-328):
     // block-SAD (north_star) or the reference's own Farneback flow
     if (want_m && P.motion_mode == VQA_MOTION_SAD) {
@@ -1029,10 +1036,12 @@ static int complexity_submit_body(vqa_ctx *c, const uint8_t *frames, const uint8
         launch_orb64(st, dframes, n, h, w, frame_stride, row_stride, T64.xofs, T64.xa, T64.yofs, T64.yb, T64.mode, res);
     }
     if (overlap) {
-        HIPCHK(c, hipEventRecord(c->ev_join[0], st_sad));
-        HIPCHK(c, hipEventRecord(c->ev_join[1], st_canny));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[0], 0));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[1], 0));
+        hipStream_t ss[3] = {st_sad, st_canny, st_dct};
+        for (int i = 0; i < 3; i++) {
+            if (!use_side[i]) continue;
+            HIPCHK(c, hipEventRecord(c->ev_join[i], ss[i]));
+            HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
+        }
     }
     c->last_n = n; c->last_has_full = need_full; c->last_has_planes = need_planes; // (debug planes show the last slice)
     return VQA_OK;
