@@ -90,8 +90,8 @@ typedef enum vqa_mem_kind {
 #define VQA_MOTION_SAD       0 /* 16x16 block-SAD full search (north_star; default)          */
 #define VQA_MOTION_FARNEBACK 1 /* cv2.calcOpticalFlowFarneback(.., 0.5, 3, 15, 3, 5, 1.2, 0)
                                   mean magnitude — what the reference computes (:340-343).
-                                  Scratch on the device: 52 bytes per pixel and pair of a chunk,
-                                  chunks of up to 12 GiB (64 pairs of 1080p = 6.9 GB), kept by
+                                  Scratch on the device: 59 bytes per pixel and pair of a chunk,
+                                  chunks of up to 12 GiB (64 pairs of 1080p = 7.8 GB), kept by
                                   the ctx until vqa_destroy                                   */
 
 /* ssim_mode */

@@ -40,6 +40,7 @@ struct vqa_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // VQA_OPT_OVERLAP: block-SAD, the Canny chain and the full-frame DCT on their own streams
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fb_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // Farneback: expansions of level k ready (0..3), planes ready (4), chunk done (5)
     std::string last_err;
     // options (vqa_set_option)
     bool opt_overlap = true, opt_hyst_stats = false;
@@ -429,8 +430,8 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
     levels = k;
     const fb_poly PC = fb_poly_consts();
     const size_t P = (size_t)h * w;
-    // per pair ~52 B/pixel of scratch (planes: blur tmp 4 + blurred 4 + level image 4 + expansion 20; pairs: two
-    // flow fields 16; + 20 for the products of the lab build's two-kernel form); a chunk stays under ~12 GiB of the
+    // per pair ~59 B/pixel of scratch (planes: blur tmp 4 + blurred 4 + level image 4 + expansions of every level 26.7;
+    // pairs: two flow fields 16; + 20 for the products of the lab build's two-kernel form); a chunk stays under ~12 GiB of the
     // 288: a 64-frame 1080p batch is ONE chunk (round 3's 3 GiB cut it into 21 + 21 + 21 + 1 pairs, and the
     // one-pair tail ran fifty launches on an empty chip)
 #ifdef VQA_AB_VARIANTS
@@ -445,13 +446,31 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
 #else
     const bool three_kernel = false;
 #endif
-    int mc = (int)((12ull << 30) / ((two_kernel ? 72 : 52) * P));
+    // Level geometry (coarse to fine: k = levels .. 0) and where each level's expansions live: with VQA_OPT_OVERLAP the level
+    // images and expansions of ALL levels are formed on a side stream (they depend on the gray planes only) while the main
+    // stream runs the flow iterations of the coarser levels - the finest level's expansion, a quarter of the pre-pass work,
+    // is ready by the time the iterations reach it.  Each level keeps its own expansion planes for that (4/3 of one level's).
+    int lwk[4], lhk[4], ksz[4];
+    double sig[4];
+    size_t Roff[4], Rtot = 0;
+    for (k = levels; k >= 0; k--) {
+        scale = 1;
+        for (int i = 0; i < k; i++) scale *= pyr_scale;
+        sig[k] = (1. / scale - 1) * 0.5;
+        ksz[k] = (int)std::lrint(sig[k] * 5) | 1;
+        if (ksz[k] < 3) ksz[k] = 3;
+        lwk[k] = (int)std::lrint(w * scale);
+        lhk[k] = (int)std::lrint(h * scale);
+    }
+    int mc = (int)((12ull << 30) / ((two_kernel ? 72 : 59) * P));
     mc = mc < 1 ? 1 : (mc > n ? n : mc);
+    for (k = levels; k >= 0; k--) { Roff[k] = Rtot; Rtot += (size_t)5 * lhk[k] * lwk[k] * (mc + 1); }
+    const bool piped = c->opt_overlap && !two_kernel && !three_kernel;
     int rc;
     if ((rc = ensure(c, c->fb_tmp, sizeof(float) * P * (mc + 1)))) return rc;
     if ((rc = ensure(c, c->fb_blur, sizeof(float) * P * (mc + 1)))) return rc;
     if ((rc = ensure(c, c->fb_img, sizeof(float) * P * (mc + 1)))) return rc;
-    if ((rc = ensure(c, c->fb_R, sizeof(float) * 5 * P * (mc + 1)))) return rc;
+    if ((rc = ensure(c, c->fb_R, sizeof(float) * Rtot))) return rc;
     if (two_kernel && (rc = ensure(c, c->fb_M, sizeof(float) * 5 * P * mc))) return rc;
     if ((rc = ensure(c, c->fb_flow0, sizeof(float) * 2 * P * mc))) return rc;
     if ((rc = ensure(c, c->fb_flow1, sizeof(float) * 2 * P * mc))) return rc;
@@ -463,43 +482,62 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
         if ((rc = ensure(c, c->fb_part, sizeof(double) * (size_t)nb * mc))) return rc;
     }
     float *tmp = (float *)c->fb_tmp.p, *blur = (float *)c->fb_blur.p, *img = (float *)c->fb_img.p;
-    float *R = (float *)c->fb_R.p;
+    float *Rall = (float *)c->fb_R.p;
 #ifdef VQA_AB_VARIANTS
     float *M = (float *)c->fb_M.p;
 #endif
     float *flow = (float *)c->fb_flow0.p, *prev_flow = (float *)c->fb_flow1.p;
+    hipStream_t sp = st; // the stream of the level images and expansions
+    if (piped) {
+        if (!c->side[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->side[0], hipStreamNonBlocking)); // block-SAD's stream: idle in this mode
+        for (int i = 0; i < 6; i++)
+            if (!c->fb_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->fb_ev[i], hipEventDisableTiming));
+        sp = c->side[0];
+        HIPCHK(c, hipEventRecord(c->fb_ev[4], st)); // the gray planes exist in st's order
+        HIPCHK(c, hipStreamWaitEvent(sp, c->fb_ev[4], 0));
+    }
+    // the level image and the expansion of level k for the chunk's planes, on stream s
+    auto expand = [&](hipStream_t s, int k, const uint8_t *g0, int planes) -> int {
+        const int lw = lwk[k], lh = lhk[k];
+        const float *level_img = img;
+        const fb_taps K = fb_gauss_taps(ksz[k], sig[k]);
+        if (lw != w || lh != h) {
+            fb_resize_tabs T;
+            if (int r2 = get_fb_tabs(c, h, w, lh, lw, T)) return r2;
+            if (three_kernel || !launch_fb_level(s, g0, gp, plane_stride, planes, h, w, K, &T, img, lh, lw)) {
+                launch_fb_blur(s, g0, gp, plane_stride, planes, h, w, K, T.cols, T.nc, T.rows, T.nr, tmp, blur);
+                launch_fb_resize(s, blur, h, w, 1, img, lh, lw, planes, T, 1.f, false);
+            }
+        } else if (three_kernel || !launch_fb_level(s, g0, gp, plane_stride, planes, h, w, K, nullptr, img, lh, lw)) {
+            launch_fb_blur(s, g0, gp, plane_stride, planes, h, w, K, nullptr, 0, nullptr, 0, tmp, blur);
+            level_img = blur;
+        }
+        launch_fb_polyexp(s, level_img, planes, lh, lw, PC, Rall + Roff[k]);
+        return VQA_OK;
+    };
     for (int a = 0; a < n; a += mc) {
         const int pairs = (n - a) < mc ? (n - a) : mc, planes = pairs + 1;
         const uint8_t *g0 = gray + (int64_t)a * plane_stride;
+        if (piped) {
+            // the previous chunk's iterations still read the expansion planes: the side stream waits for them
+            if (a > 0) HIPCHK(c, hipStreamWaitEvent(sp, c->fb_ev[5], 0));
+            for (k = levels; k >= 0; k--) {
+                if ((rc = expand(sp, k, g0, planes))) return rc;
+                HIPCHK(c, hipEventRecord(c->fb_ev[k], sp));
+            }
+        }
         int pw = 0, ph = 0;
         for (k = levels; k >= 0; k--) {
-            scale = 1;
-            for (int i = 0; i < k; i++) scale *= pyr_scale;
-            const double sigma = (1. / scale - 1) * 0.5;
-            int smooth_sz = (int)std::lrint(sigma * 5) | 1;
-            if (smooth_sz < 3) smooth_sz = 3;
-            const int lw = (int)std::lrint(w * scale), lh = (int)std::lrint(h * scale);
-            // flow of this level: zero at the coarsest, else the coarser level's flow resized and doubled — formed
-            // inside the level's first product rebuild (its only reader), never written out
+            const int lw = lwk[k], lh = lhk[k];
+            const float *R = Rall + Roff[k];
+            // flow of this level: zero at the coarsest, else the coarser level's flow resized and doubled
             fb_resize_tabs TF;
             const bool coarsest = (k == levels);
             // exact 2x decimation cannot occur here (this is an upscale), so the bilinear tables always apply
             if (!coarsest && (rc = get_fb_tabs(c, ph, pw, lh, lw, TF))) return rc;
             // every plane once: blur (only where the resize will sample), resize to the level, polynomial expansion
-            const float *level_img = img;
-            const fb_taps K = fb_gauss_taps(smooth_sz, sigma);
-            if (lw != w || lh != h) {
-                fb_resize_tabs T;
-                if ((rc = get_fb_tabs(c, h, w, lh, lw, T))) return rc;
-                if (three_kernel || !launch_fb_level(st, g0, gp, plane_stride, planes, h, w, K, &T, img, lh, lw)) {
-                    launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, K, T.cols, T.nc, T.rows, T.nr, tmp, blur);
-                    launch_fb_resize(st, blur, h, w, 1, img, lh, lw, planes, T, 1.f, false);
-                }
-            } else if (three_kernel || !launch_fb_level(st, g0, gp, plane_stride, planes, h, w, K, nullptr, img, lh, lw)) {
-                launch_fb_blur(st, g0, gp, plane_stride, planes, h, w, K, nullptr, 0, nullptr, 0, tmp, blur);
-                level_img = blur;
-            }
-            launch_fb_polyexp(st, level_img, planes, lh, lw, PC, R);
+            if (piped) HIPCHK(c, hipStreamWaitEvent(st, c->fb_ev[k], 0));
+            else if ((rc = expand(st, k, g0, planes))) return rc;
 #ifdef VQA_AB_VARIANTS
             if (two_kernel) {
                 launch_fb_update_first(st, R, coarsest ? nullptr : prev_flow, ph, pw, TF, (float)(1. / pyr_scale), pairs, lh, lw, M);
@@ -511,7 +549,7 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
             } else
 #endif
             {
-                // The coarser level's result (prev_flow) is upsampled and doubled into `flow` by the resize kernel (8 B/pixel
+                // The coarser level's result (prev_flow) is upsampled and doubled into `flow` by the upsample kernel (8 B/pixel
                 // written once per level: forming it inside the first iteration instead cost that iteration 70 % more time
                 // than the write - the eight dependent loads per row sit on the march's critical path); the iterations then
                 // ping-pong between the two buffers, and prev_flow ends up naming this level's result.
@@ -537,6 +575,7 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
 #endif
         launch_fb_mag_finalize(st, (const double *)c->fb_part.p, fb_iter_blocks(pairs, h, w), pairs, h, w, a > 0 || first_has_prev,
                                res + a);
+        if (piped && a + mc < n) HIPCHK(c, hipEventRecord(c->fb_ev[5], st));
     }
     return VQA_OK;
 }
@@ -667,6 +706,8 @@ int vqa_destroy(vqa_ctx *c)
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < 6; i++)
+        if (c->fb_ev[i]) (void)hipEventDestroy(c->fb_ev[i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return VQA_OK;

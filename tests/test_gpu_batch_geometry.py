@@ -132,11 +132,12 @@ def test_c3ref_batch_64x1080p_reference_definitions(engine):
 
 
 def test_farneback_chunk_seam_at_1080p(engine):
-    """The Farneback pyramid works on chunks of at most 12 GiB of scratch (119 pairs of 1080p): a 125-pair batch is two
-    chunks (119 + 6) with different strip geometries, partial-sum counts and a halo plane at the seam.  Oracle at both
-    sides of the seam and at both ends; every pair positive."""
+    """The Farneback pyramid works on chunks of at most 12 GiB of scratch (105 pairs of 1080p at 59 bytes per pixel and
+    pair): a 125-pair batch is two chunks (105 + 20) with different strip geometries, partial-sum counts, a halo plane at
+    the seam and - with VQA_OPT_OVERLAP - the second chunk's expansions waiting for the first chunk's iterations.  Oracle at
+    both sides of the seam and at both ends; every pair positive."""
     from rtvqa_amd import _native as N
-    h, w, B, positions = 1080, 1920, 125, [0, 118, 119, 124]
+    h, w, B, positions = 1080, 1920, 125, [0, 104, 105, 124]
     keep = sorted(set(positions) | set(j + 1 for j in positions))
     ref_all, dist_all, host = _resident_stream(engine, h, w, B, keep)
     del ref_all
