@@ -19,11 +19,11 @@ cp profiles/${R}_*_pmc.json $ROOT/gpurun_out/ 2>/dev/null
 bash scripts/gpu_profile.sh final_c3 --steps 10 --warmup 2 || exit 1
 bash scripts/gpu_profile.sh final_c2 --workload c2 --steps 10 --warmup 2 --cpu-sample 32 || exit 1
 bash scripts/gpu_profile.sh final_c4 --workload c4 --steps 5 --warmup 2 --cpu-sample 8 || exit 1
-bash scripts/gpu_profile.sh final_c3ref --workload c3ref --steps 3 --warmup 1 --cpu-sample 8 || exit 1
+bash scripts/gpu_profile.sh final_c3ref --workload c3ref --steps 10 --warmup 2 --cpu-sample 8 || exit 1
 bash scripts/gpu_profile.sh final_c3full --dct-mode full --steps 5 --warmup 2 --cpu-sample 0 --e2e-steps 0 || exit 1
 bash scripts/gpu_profile.sh final_c2ff --workload c2 --steps 10 --warmup 2 --ssim-mode ffmpeg --cpu-sample 0 --e2e-steps 0 || exit 1
 bash scripts/gpu_profile.sh final_c3noise --content noise --steps 5 --warmup 2 --cpu-sample 0 --e2e-steps 0 || exit 1
-bash scripts/gpu_profile.sh final_c3fb --motion farneback --batch 64 --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0 || exit 1
+bash scripts/gpu_profile.sh final_c3fb --motion farneback --batch 64 --steps 10 --warmup 2 --cpu-sample 0 --e2e-steps 0 || exit 1
 bash scripts/gpu_valu.sh ${R}_c3 --steps 2 --warmup 1 --no-verify || exit 1
 cp profiles/${R}_c3_valu.json $ROOT/gpurun_out/ 2>/dev/null
 echo round-end done
