@@ -12,6 +12,8 @@ nobody in this repository wrote, so what it computes pins the oracle where the t
   * Shannon entropy of a plane (complexity_metrics.py:413-414, :467-473)       -> the product's f32 tails, 1e-6 / 1e-5
   * FAST-9/16 detection without NMS (corner_fast(n=9, threshold=20) on the integer-valued float image; the corner
     test cv2.ORB_create's detector applies, complexity_metrics.py:386-387)     -> oracle fast9(nonmax=False), exact map
+  * 2x2 local means rounded half up (transform.downscale_local_mean): the arithmetic of the exact-halving shortcut of
+    cv2.resize (INTER_LINEAR -> INTER_AREA at scale 2), pinned exactly;
   * float64 bilinear resize with half-pixel centres and edge clamping (transform.resize(order=1, mode="edge",
     anti_aliasing=False)): a GEOMETRY pin for cv2.resize INTER_LINEAR (complexity_metrics.py:359,404) - OpenCV's 11-bit
     fixed point must stay within 1 grey level of it; it does not pin OpenCV's rounding
@@ -152,7 +154,7 @@ def stage2(tmp):
     from skimage.feature import corner_fast
     from skimage.measure import shannon_entropy
     from skimage.metrics import mean_squared_error, peak_signal_noise_ratio, structural_similarity
-    from skimage.transform import resize
+    from skimage.transform import resize, downscale_local_mean
 
     meta = json.load(open(os.path.join(tmp, "meta.json")))
     out = {"versions": {"skimage": skimage.__version__, "scipy": scipy.__version__, "numpy": np.__version__, "pillow": PIL.__version__,
@@ -192,6 +194,10 @@ def stage2(tmp):
         sob = np.abs(scipy.ndimage.sobel(gi, axis=1, mode="nearest")) + np.abs(scipy.ndimage.sobel(gi, axis=0, mode="nearest"))
         sh, sw = sob.shape
         wts = (np.arange(sh, dtype=np.int64)[:, None] * 31 + np.arange(sw, dtype=np.int64)[None, :] * 17 + 1) % 1009
+        # exact halving: cv2.resize(INTER_LINEAR) takes INTER_AREA's 2x2 mean there, (a + b + c + d + 2) >> 2 = floor(mean + 0.5)
+        he, we = g0.shape[0] & ~1, g0.shape[1] & ~1
+        a2 = np.floor(downscale_local_mean(g0[:he, :we], (2, 2)) + 0.5).astype(np.int64)
+        w2 = (np.arange(he // 2, dtype=np.int64)[:, None] * 31 + np.arange(we // 2, dtype=np.int64)[None, :] * 17 + 1) % 1009
         out["frames"][m["name"]] = dict(
             gray_entropy=float(shannon_entropy(g0.astype(np.uint8))),
             color_entropy_sum=float(sum(shannon_entropy(bgr[..., c]) for c in range(3))),
@@ -205,6 +211,7 @@ def stage2(tmp):
             gray_vs_float_maxdiff=float(np.abs(lum_f - g0).max()),
             sobel_l1_sum=int(sob.sum()), sobel_l1_max=int(sob.max()), sobel_l1_crc=int((sob.astype(np.int64) * wts).sum()),
             sobel_l1_border_sum=int(sob[0].sum() + sob[-1].sum() + sob[:, 0].sum() + sob[:, -1].sum()),
+            area2_sum=int(a2.sum()), area2_max=int(a2.max()), area2_crc=int((a2 * w2).sum()),
             resize_float=[round(float(v), 6) for v in rs.ravel()])
     json.dump(out, open(os.path.join(tmp, "results.json"), "w"))
 

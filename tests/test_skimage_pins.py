@@ -177,6 +177,24 @@ def test_oracle_resize_geometry_within_one_level_of_float_bilinear(rec):
     assert np.abs(got - want).mean() < 0.3
 
 
+def _area2_fields(plane):
+    he, we = plane.shape
+    w2 = (np.arange(he, dtype=np.int64)[:, None] * 31 + np.arange(we, dtype=np.int64)[None, :] * 17 + 1) % 1009
+    p = plane.astype(np.int64)
+    return int(p.sum()), int(p.max()), int((p * w2).sum())
+
+
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_oracle_exact_halving_equals_rounded_local_means(rec):
+    """cv2.resize(INTER_LINEAR) at an exact factor of two takes INTER_AREA's shortcut: the 2x2 mean rounded half up,
+    (a + b + c + d + 2) >> 2.  scikit-image's downscale_local_mean gives the float means; floor(mean + 0.5) must be the
+    oracle's plane EXACTLY (sum, maximum and a position-weighted checksum of every pixel)."""
+    g0, _ = gp.gray_for(FRAME_CASE[rec["name"]])
+    he, we = g0.shape[0] & ~1, g0.shape[1] & ~1
+    got = co.resize_linear(np.ascontiguousarray(g0[:he, :we]), we // 2, he // 2)
+    assert _area2_fields(got) == (rec["area2_sum"], rec["area2_max"], rec["area2_crc"])
+
+
 # ---------------------------------------------------------------------------------------- GPU half
 @pytest.mark.gpu
 @pytest.mark.parametrize("rec", G["pairs"], ids=pid)
@@ -223,3 +241,17 @@ def test_gpu_histogram_and_dct_kernels_equal_skimage_and_scipy(engine, rec):
     r0 = engine.complexity(fr[:1], mask=N.M_GRAY_HIST | N.M_COLOR_HIST)[0]
     assert abs(float(cm._gray_entropy(r0["hist_gray"])) - rec["gray_entropy"]) <= 1e-6 * rec["gray_entropy"]
     assert abs(float(cm._color_entropy(r0["hist_bgr"])) - rec["color_entropy_sum"]) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec", G["frames"], ids=pid)
+def test_gpu_exact_halving_equals_rounded_local_means(engine, rec):
+    """The device's resize at an exact factor of two (plane A = resize(gray(frame)), vqa_debug_read_plane) against the same
+    scikit-image pin: the rounded 2x2 means, every pixel."""
+    from rtvqa_amd import _native as N
+    fr = frames_of(rec)
+    he, we = fr.shape[1] & ~1, fr.shape[2] & ~1
+    crop = np.ascontiguousarray(fr[:1, :he, :we])
+    engine.complexity(crop, mask=N.M_DCT, resize=(we // 2, he // 2), dct_mode=N.DCT_BLOCK8)
+    got = engine.debug_plane(0, 0, he // 2, we // 2)
+    assert _area2_fields(got) == (rec["area2_sum"], rec["area2_max"], rec["area2_crc"])
