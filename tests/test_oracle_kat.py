@@ -323,8 +323,14 @@ def test_farneback_c_and_numpy_restatements_agree():
 
 
 def test_farneback_expansion_constants():
+    import scipy.signal
     g, xg, xxg, ig = co.fb_prepare()
     assert abs(g.sum() - 1) < 1e-6 and np.allclose(g, g[::-1]) and np.allclose(xg, -xg[::-1])
+    # FarnebackPrepareGaussian's taps = the unit-sum Gaussian window (SciPy's definition), x g and x^2 g its moments
+    win = scipy.signal.windows.gaussian(11, 1.2)
+    win /= win.sum()
+    x5 = np.arange(-5, 6)
+    assert np.allclose(g, win, rtol=2e-7) and np.allclose(xg, x5 * win, rtol=3e-7, atol=1e-12) and np.allclose(xxg, x5 * x5 * win, rtol=3e-7, atol=1e-12)
     G = np.zeros((6, 6))
     x = np.arange(-5, 6, dtype=np.float64)
     gg = np.outer(g.astype(np.float64), g.astype(np.float64))
