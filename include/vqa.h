@@ -13,12 +13,26 @@
  * ffmpeg subprocess); the entry points below are what a ctypes binding for that
  * path binds (INTEGRATION.md shows the stub).  Plain pointers and sizes only —
  * no torch / numpy types.  Every function returns VQA_OK (0) or a negative
- * vqa_status; nothing throws; there is no global state besides the HIP runtime.
+ * vqa_status; nothing throws.
  *
  * Threading: one vqa_ctx per device per host thread.  A ctx owns one HIP stream,
  * its scratch planes and a pinned result staging area; it is NOT thread-safe.
+ * Different contexts may be used from different threads at the same time.
  * Buffers handed to a *_submit call must stay alive and unmodified until the
  * matching *_wait returns.
+ * Process-wide state, all of it: (1) the HIP runtime; (2) the table of RCCL entry
+ * points, filled once by the first vqa_comm_create* / vqa_comm_unique_id call
+ * (a C++11 function-local static: concurrent first calls are safe); (3) immutable
+ * function-local constants.  Everything mutable - scratch, cached tables, launch
+ * geometry derived from the device (queried in vqa_create), options, error text -
+ * is a field of the ctx.
+ *
+ * Memory: a ctx keeps what it has grown - scratch planes sized by the largest batch
+ * seen (Farneback: up to ~13.5 GiB), result staging, and small per-geometry tables
+ * (at most VQA_TABLE_CACHE_GEOMETRIES entries of each kind, least recently used
+ * evicted) - so that a steady stream of batches allocates nothing.  vqa_trim gives
+ * all of it back without destroying the ctx (the reference holds nothing between
+ * calls: a process pool per call, complexity_metrics.py:143-147).
  *
  * There is NO CPU fallback: vqa_create fails with VQA_ERR_NO_DEVICE when no
  * gfx950 device is visible.
@@ -49,7 +63,8 @@ extern "C" {
 #define VQA_API
 #endif
 
-#define VQA_ABI_VERSION 5
+#define VQA_ABI_VERSION 6
+#define VQA_TABLE_CACHE_GEOMETRIES 16
 
 typedef enum vqa_status {
     VQA_OK = 0,
@@ -91,8 +106,10 @@ typedef enum vqa_mem_kind {
 #define VQA_MOTION_FARNEBACK 1 /* cv2.calcOpticalFlowFarneback(.., 0.5, 3, 15, 3, 5, 1.2, 0)
                                   mean magnitude — what the reference computes (:340-343).
                                   Scratch on the device: 59 bytes per pixel and pair of a chunk,
-                                  chunks of up to 12 GiB (64 pairs of 1080p = 7.8 GB), kept by
-                                  the ctx until vqa_destroy                                   */
+                                  chunks of up to 12 GiB (64 pairs of 1080p = 7.8 GB) and never
+                                  more than 80 % of what the device has free (halved again if the
+                                  reservation still fails), kept by the ctx until vqa_trim /
+                                  vqa_destroy                                                  */
 
 /* ssim_mode */
 #define VQA_SSIM_GAUSS  0 /* 11x11 Gaussian window, sigma 1.5 (north_star)                  */
@@ -133,7 +150,12 @@ typedef struct vqa_frame_metrics {
                                     the CPU restatement of cv2.calcOpticalFlowFarneback, EXCEPT on frames where a border
                                     pixel's flow lies within float rounding of FarnebackUpdateMatrices' in-frame test
                                     (a discontinuity of the algorithm: either side is a valid evaluation; seen on
-                                    35x31 / 129x34 noise frames, 4e-4 on the mean) - there 2e-3 */
+                                    35x31 / 129x34 noise frames, 4e-4 on the mean) - there 2e-3.
+                                    NOT bit-stable across batch geometry: the column sums of the last iteration restart per
+                                    strip and the strip count follows the number of pairs in the chunk, so the same frame
+                                    pair submitted in batches of different size can differ by <= 1e-6 relative (tested);
+                                    the same batch always gives the same bits.  Every other field is independent of how
+                                    frames are batched. */
 } vqa_frame_metrics;
 
 /* One 8-bit plane inside a frame buffer (planar YUV plane, or one channel of
@@ -157,6 +179,10 @@ VQA_API const char *vqa_strerror(int status);
 VQA_API int vqa_device_count(int *count);
 VQA_API int vqa_create(int device, vqa_ctx **out);
 VQA_API int vqa_destroy(vqa_ctx *ctx);
+/* Gives back everything an idle ctx keeps between batches: every grow-only scratch buffer, the result staging and every
+ * cached table (device and pinned host memory; the streams, events and options stay).  The next submit re-grows what it
+ * needs.  VQA_ERR_STATE while a batch is pending (between a *_submit and its *_wait).                                    */
+VQA_API int vqa_trim(vqa_ctx *ctx);
 /* text of the last failing HIP call on this ctx ("" if none) */
 VQA_API const char *vqa_last_hip_error(const vqa_ctx *ctx);
 VQA_API void vqa_default_params(vqa_params *p);
@@ -179,6 +205,10 @@ VQA_API int vqa_get_option(const vqa_ctx *ctx, int option, int *value);
 /* ---- memory --------------------------------------------------------------- */
 VQA_API int vqa_alloc_pinned(vqa_ctx *ctx, size_t bytes, void **out);
 VQA_API int vqa_free_pinned(vqa_ctx *ctx, void *p);
+/* *out = 1 if p points into page-locked host memory HIP knows (vqa_alloc_pinned, hipHostMalloc, hipHostRegister, a
+ * torch tensor with pin_memory=True): a *_submit / vqa_copy_h2d from it is a true asynchronous DMA.  0 for ordinary
+ * (pageable) host memory - the host side then stages through pinned buffers of its own - and for device memory.       */
+VQA_API int vqa_host_is_pinned(vqa_ctx *ctx, const void *p, int *out);
 VQA_API int vqa_alloc_device(vqa_ctx *ctx, size_t bytes, void **out);
 VQA_API int vqa_free_device(vqa_ctx *ctx, void *p);
 /* async on the ctx stream; host side should be pinned for true overlap */

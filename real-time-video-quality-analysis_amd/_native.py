@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH") or os.path.join(_HERE, "csrc", "libvqa_hip.so")
 LAB_LIB_PATH = os.path.join(_HERE, "csrc", "lab", "libvqa_hip_lab.so")
 
-VQA_ABI_VERSION = 5
+VQA_ABI_VERSION = 6
+VQA_TABLE_CACHE_GEOMETRIES = 16
 
 VQA_OK = 0
 VQA_ERR_INVALID = -1
@@ -87,6 +88,7 @@ SIGNATURES = {
     "vqa_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "vqa_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "vqa_destroy": (C.c_int, [C.c_void_p]),
+    "vqa_trim": (C.c_int, [C.c_void_p]),
     "vqa_last_hip_error": (C.c_char_p, [C.c_void_p]),
     "vqa_default_params": (None, [C.POINTER(VqaParams)]),
     "vqa_build_flavour": (C.c_int, []),
@@ -94,6 +96,7 @@ SIGNATURES = {
     "vqa_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "vqa_alloc_pinned": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vqa_free_pinned": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vqa_host_is_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "vqa_alloc_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vqa_free_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vqa_copy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

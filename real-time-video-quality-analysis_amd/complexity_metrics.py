@@ -18,8 +18,10 @@ Differences that are deliberate:
     frames is one kernel launch instead of one pickled frame per pool task;
   * motion is block-SAD by default (BASELINE.json north_star); set_motion_mode("farneback") or
     VQA_MOTION=farneback selects the reference's own Farneback flow (SURVEY.md §8f N4);
+  * a clip is read ONCE (stream.py): one fused pass serves all seven series, where the reference decodes
+    three times and maps seven times; host clips travel through pinned memory (the caller's, or a ring).
 No metric is ever computed on the CPU here; without the HIP library this module
-raises on first use.
+raises on first use.  Like the engines it drives, the module is per process and NOT thread-safe.
 """
 import functools
 import logging
@@ -28,34 +30,13 @@ import os
 import numpy as np
 
 from . import _native as N
-from .engine import DeviceFrames, Engine
-from .pooling import pooling_weights, shard_range
+from . import stream, tails
+from .engine import DeviceFrames
+from .pooling import pooling_weights
 from .pooling import smooth_data as _ewm
+from .stream import get_engine, get_engine_pair, release_buffers, selected_indices  # noqa: F401 (re-exported)
 
 logger = logging.getLogger(__name__)
-
-_engines = {}
-
-
-def get_engine(device=None):
-    """One Engine per (process, device).  Default device: LOCAL_RANK, else 0."""
-    if device is None:
-        device = int(os.environ.get("VQA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    if device not in _engines:
-        _engines[device] = Engine(device)
-    return _engines[device]
-
-
-_engine_pairs = {}
-
-
-def get_engine_pair(device=None):
-    """Two engines (= two HIP streams with their own staging buffers) on one device: while batch k's kernels
-    run on one, batch k+1 crosses PCIe on the other.  Used for host-resident clips longer than one batch."""
-    first = get_engine(device)
-    if first.device not in _engine_pairs:
-        _engine_pairs[first.device] = Engine(first.device)
-    return first, _engine_pairs[first.device]
 
 
 # ---------------------------------------------------------------------------
@@ -88,11 +69,6 @@ def _open_frames(video):
 
 def _num_frames(fr):
     return fr.n if isinstance(fr, DeviceFrames) else fr.shape[0]
-
-
-def selected_indices(num_frames, frame_interval):
-    """0-based indices read_frame_pairs keeps: 1-based count % interval == 0 (:103-104)."""
-    return np.arange(frame_interval - 1, num_frames, frame_interval)
 
 
 def read_frame_pairs(video_path, frame_interval=10):
@@ -138,24 +114,8 @@ def process_frame_interval_for_parallel(timestamps):
 # ---------------------------------------------------------------------------
 # counts -> reference scalars (the float tails the reference runs in NumPy)
 # ---------------------------------------------------------------------------
-def _gray_entropy(counts):
-    hist = counts.astype(np.float32).reshape(256, 1)      # calcHist returns float32 (256,1)
-    hist = hist / hist.sum()                              # :413
-    return -np.sum(hist[hist > 0] * np.log2(hist[hist > 0]))  # :414
-
-
-def _color_entropy(counts_bgr):
-    hist_b, hist_g, hist_r = (counts_bgr[c].astype(np.float32).reshape(256, 1) for c in range(3))
-    sb, sg, sr = hist_b.sum(), hist_g.sum(), hist_r.sum()
-    if sb == 0 or sg == 0 or sr == 0:                     # :464-465
-        return float("nan")
-    hist_b, hist_g, hist_r = hist_b / sb, hist_g / sg, hist_r / sr
-    return -(np.sum(hist_b * np.log2(hist_b + 1e-8)) + np.sum(hist_g * np.log2(hist_g + 1e-8)) +
-             np.sum(hist_r * np.log2(hist_r + 1e-8)))     # :471-473
-
-
-_SQRT_K = np.sqrt(np.arange(129, dtype=np.float64))
-
+_gray_entropy = tails.gray_entropy      # :413-414
+_color_entropy = tails.color_entropy    # :464-473
 
 _MOTION_MODES = {"sad": N.MOTION_SAD, "farneback": N.MOTION_FARNEBACK}
 _motion_mode = _MOTION_MODES[os.environ.get("VQA_MOTION", "sad")]
@@ -168,35 +128,16 @@ def set_motion_mode(mode):
     _motion_mode = _MOTION_MODES[mode]
 
 
-def _motion_magnitude(rec):
-    if _motion_mode == N.MOTION_FARNEBACK:
-        return np.float32(rec["flow_mag_mean"])  # np.mean of a float32 array is a float32 (:343)
-    nb = int(rec["sad_blocks"])
-    if nb == 0:
-        return np.float32(0.0)
-    return np.float32(np.dot(rec["mv_d2_hist"].astype(np.float64), _SQRT_K) / nb)
-
-
 def _scalar(kind, rec):
-    if kind == "dct":
-        return np.float32(rec["dct_energy"])
-    if kind == "temporal":
-        return np.float32(rec["temporal_dct_l1"])
-    if kind == "hist":
-        return _gray_entropy(rec["hist_gray"])
-    if kind == "color":
-        return _color_entropy(rec["hist_bgr"])
-    if kind == "edge":
-        return np.int64(rec["edge_count"])
-    if kind == "motion":
-        return _motion_magnitude(rec)
-    if kind == "orb":
-        return int(rec["orb_keypoints"])
-    raise KeyError(kind)
+    return tails.scalar(kind, rec, _motion_mode)
 
 
-_MASK = {"dct": N.M_DCT, "temporal": N.M_TEMPORAL_DCT, "hist": N.M_GRAY_HIST, "color": N.M_COLOR_HIST,
-         "edge": N.M_EDGE, "motion": N.M_MOTION, "orb": N.M_ORB}
+def _scalars(kind, rec):
+    """the batch form: same values, same types, one pass over the records (tails.py)"""
+    return tails.scalars(kind, rec, _motion_mode)
+
+
+_MASK = stream.MASK
 
 
 # ---------------------------------------------------------------------------
@@ -309,7 +250,7 @@ def process_in_batches(frames, process_func, num_workers, batch_size=100, **kwar
             results.extend(call(item) for item in batch)
             continue
         rec = eng.complexity(np.stack(items), mask=_MASK[kind], resize=resize)
-        results.extend(_scalar(kind, r) for r in rec)
+        results.extend(_scalars(kind, rec))
     return results
 
 
@@ -326,14 +267,14 @@ def _motion_batch(eng, pairs):
     if chained:
         arr = np.stack([np.asarray(pairs[j][0]) for j in live])
         rec = eng.complexity(arr, prev0=np.asarray(pairs[live[0]][1]), mask=N.M_MOTION, motion_mode=_motion_mode)
-        for k, j in enumerate(live):
-            out[j] = _scalar("motion", rec[k])
+        for j, v in zip(live, _scalars("motion", rec)):
+            out[j] = v
     else:
         # arbitrary pairs: interleave (prev, curr) and keep every second result
         arr = np.stack([np.asarray(pairs[j][s]) for j in live for s in (1, 0)])
         rec = eng.complexity(arr, mask=N.M_MOTION, motion_mode=_motion_mode)
-        for k, j in enumerate(live):
-            out[j] = _scalar("motion", rec[2 * k + 1])
+        for j, v in zip(live, _scalars("motion", rec[1::2])):
+            out[j] = v
     return out
 
 
@@ -342,7 +283,7 @@ def _motion_batch(eng, pairs):
 # ---------------------------------------------------------------------------
 def complexity_series(video, resize_width, resize_height, frame_interval=10, batch_size=100, engine=None,
                       dct_mode=N.DCT_AUTO, mask=N.M_ALL, shard=None):
-    """Per-frame series for the frames the reference measures, from ONE fused pass.
+    """Per-frame series for the frames the reference measures, from ONE fused pass (stream.run).
 
     Returns dict kind -> list, each in the reference's sample order:
       motion/dct/hist/edge/orb/color : T-1 samples (selected frames S_1..S_{T-1}; :268-290)
@@ -350,60 +291,11 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
     shard=(rank, world): only this rank's contiguous range of the T-1 samples is computed (the
     shard also reads the ONE selected frame before its first, as the pair metrics' halo); the lists then hold
     that range only and out["range"] = (lo, hi) gives its place in the whole series.
-    """
-    fr = _open_frames(video)
-    idx = selected_indices(_num_frames(fr), frame_interval)
-    out = {k: [] for k in ("motion", "dct", "hist", "edge", "orb", "color", "temporal")}
-    lo, hi = shard_range(max(len(idx) - 1, 0), *shard) if shard is not None else (0, max(len(idx) - 1, 0))
-    out["range"] = (lo, hi)
-    if len(idx) < 2 or hi <= lo:  # unopenable / too short: empty series, as the reference's empty pair list (:95-97)
-        return out
-    on_device = isinstance(fr, DeviceFrames)
-    if engine is not None or len(idx) - 1 <= batch_size:
-        engs = [engine or get_engine()]
-    else:
-        # several batches: two contexts, batch k + 1 is submitted before batch k is waited for.  A host clip's copy then
-        # overlaps the other context's kernels; a device-resident clip's kernels keep the chip busy across the wait
-        # (bench.py's --inflight 2: +5 % on the full suite)
-        own = getattr(fr, "_owner", None) if on_device else None  # a DeviceBuffer knows its engine's device; a torch tensor its index
-        dev = (own.engine.device if hasattr(own, "engine") else getattr(getattr(own, "device", None), "index", None)) if own is not None else None
-        engs = list(get_engine_pair(dev))
-    params = engs[0].make_params(resize=(resize_width, resize_height), dct_mode=dct_mode, motion_mode=_motion_mode)
-    sel = idx[1 + lo:1 + hi]
-    prev_i = idx[lo]
-    first_global = lo == 0
-
-    def collect(eng, a):
-        rec = eng.complexity_wait()
-        for j, r in enumerate(rec):
-            for kind in ("motion", "dct", "hist", "edge", "orb", "color"):
-                if mask & _MASK[kind]:
-                    out[kind].append(_scalar(kind, r))
-            # the reference's first pair only primes prev_gray_frame (:533-537)
-            if (mask & N.M_TEMPORAL_DCT) and not (first_global and a == 0 and j == 0):
-                out["temporal"].append(_scalar("temporal", r))
-
-    pending = []
-    for k, a in enumerate(range(0, len(sel), batch_size)):
-        chunk = sel[a:a + batch_size]
-        if on_device:
-            # every frame_interval-th frame, zero-copy: the batch is a strided view of the resident clip
-            batch = DeviceFrames(fr.ptr + int(chunk[0]) * fr.frame_stride, len(chunk), fr.h, fr.w,
-                                 frame_stride=fr.frame_stride * frame_interval, row_stride=fr.row_stride,
-                                 owner=fr, channels=fr.channels)
-            prev0 = fr.frame(int(prev_i))
-        else:
-            batch = fr[int(chunk[0]):int(chunk[-1]) + 1:frame_interval]  # strided view: only selected frames are uploaded
-            prev0 = np.asarray(fr[prev_i])
-        eng = engs[k % len(engs)]
-        if len(pending) == len(engs):
-            collect(*pending.pop(0))
-        eng.complexity_submit(batch, prev0, mask, params)
-        pending.append((eng, a))
-        prev_i = chunk[-1]
-    while pending:
-        collect(*pending.pop(0))
-    return out
+    Chunks of up to batch_size samples alternate between two engines of the device (one with Farneback motion: its
+    scratch is GiB-sized per context); only the selected frames of a host clip cross PCIe, from the caller's pinned
+    memory or through the pinned ring."""
+    cx = stream.Complexity((resize_width, resize_height), frame_interval, mask, dct_mode, _motion_mode, shard)
+    return stream.run(_open_frames(video), complexity=cx, batch_size=batch_size, engine=engine)[1]
 
 
 _DCT_MODES = {None: N.DCT_AUTO, "auto": N.DCT_AUTO, "full": N.DCT_FULL, "block8": N.DCT_BLOCK8}
@@ -419,16 +311,9 @@ def calculate_temporal_dct(video_path, resize_width, resize_height, frame_interv
     return np.mean(sm) if len(sm) > 0 else 0.0
 
 
-def calculate_average_scene_complexity(video_path, resize_width, resize_height, frame_interval=10,
-                                       smoothing_factor=0.8, num_workers=None, batch_size=100, fps=30.0,
-                                       dct_mode=None):
-    """complexity_metrics.py:246-310.  Returns the 8-tuple in the reference's order (:301-310):
-    (motion, dct, histogram, edge, orb, colour_histogram, temporal_dct, framerate_variation).
-    `video_path` may be a .npy path, an ndarray [N,H,W,3] or DeviceFrames; `fps` stands in for the container's
-    timestamps (:66) and `dct_mode` is as for calculate_temporal_dct."""
-    s = complexity_series(video_path, resize_width, resize_height, frame_interval, batch_size,
-                          dct_mode=_DCT_MODES[dct_mode])
-
+def pool_series(s, video_path, frame_interval=10, smoothing_factor=0.8, num_workers=None, batch_size=100, fps=30.0):
+    """The pooling half of calculate_average_scene_complexity (:297-310): EWM-smooth and mean every series, the
+    frame-rate variation from the timestamps; returns the 8-tuple in the reference's order."""
     def pooled(x):
         with np.errstate(invalid="ignore"), _quiet_empty_mean():
             return np.mean(smooth_data(x, smoothing_factor))
@@ -440,6 +325,18 @@ def calculate_average_scene_complexity(video_path, resize_width, resize_height, 
     framerate_variation = process_in_batches(timestamp_pairs, process_frame_interval_for_parallel, num_workers, batch_size)
     return (pooled(s["motion"]), pooled(s["dct"]), pooled(s["hist"]), pooled(s["edge"]), pooled(s["orb"]),
             pooled(s["color"]), temporal_dct_complexity, pooled(framerate_variation))
+
+
+def calculate_average_scene_complexity(video_path, resize_width, resize_height, frame_interval=10,
+                                       smoothing_factor=0.8, num_workers=None, batch_size=100, fps=30.0,
+                                       dct_mode=None):
+    """complexity_metrics.py:246-310.  Returns the 8-tuple in the reference's order (:301-310):
+    (motion, dct, histogram, edge, orb, colour_histogram, temporal_dct, framerate_variation).
+    `video_path` may be a .npy path, an ndarray [N,H,W,3] or DeviceFrames; `fps` stands in for the container's
+    timestamps (:66) and `dct_mode` is as for calculate_temporal_dct."""
+    s = complexity_series(video_path, resize_width, resize_height, frame_interval, batch_size,
+                          dct_mode=_DCT_MODES[dct_mode])
+    return pool_series(s, video_path, frame_interval, smoothing_factor, num_workers, batch_size, fps)
 
 
 def calculate_average_scene_complexity_sharded(video_path, resize_width, resize_height, frame_interval=10,

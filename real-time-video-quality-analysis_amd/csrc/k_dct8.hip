@@ -460,25 +460,27 @@ static void launch_dct8_v(hipStream_t st, dim3 grid, const uint8_t *planes, int 
 // chunks give the dispatcher finer grains at the tail of the grid.  Measured on 256 x 1080p and 64 x 2160p: 12..24
 // frames per chunk are within 2 % of each other and 3-5 % better than one grid-filling round of 43; so: 16, shrunk
 // until the grid has at least two waves per wave slot of the chip.
-static int dct_march_chunk(int n, int nw)
+static int dct_march_chunk(int n, int nw, int slots)
 {
-    { static const int v = ab_knob("VQA_DCT_FCH", 0); if (v > 0) return v < n ? v : n; } // lab build: tuning knob
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 256, per_cu = 3;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dct8_march<true, true, false, false>, 256, 0) != hipSuccess || per_cu < 1)
-            per_cu = 3;
-        slots = cus * per_cu * 4; // waves
-    }
+    { static const int v = ab_knob("VQA_DCT_FCH", 0); if (v > 0) return v < n ? v : n; } // lab build: tuning knob (a constant 0 in the shipped build)
     int fch = n < 16 ? n : 16;
     while (fch > 1 && (long)((n + fch - 1) / fch) * nw < 2L * slots) fch = (fch + 1) / 2;
     return fch;
 }
 
+int dct8_wave_slots()
+{
+    int dev = 0, cus = 256, per_cu = 3;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dct8_march<true, true, false, false>, 256, 0) != hipSuccess || per_cu < 1)
+        per_cu = 3;
+    (void)hipGetLastError();
+    return cus * per_cu * 4; // waves
+}
+
 void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
-                 bool energy, bool temporal, bool first_has_prev, double *partials, vqa_frame_metrics *res)
+                 bool energy, bool temporal, bool first_has_prev, double *partials, vqa_frame_metrics *res, int wave_slots)
 {
     if (n <= 0 || (!energy && !temporal)) return;
 #ifdef VQA_AB_VARIANTS
@@ -486,7 +488,7 @@ void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane
 #endif
     { // frame-marching kernel: one transform per frame
         const int nblk = ((w + 7) / 8) * ((h + 7) / 8), nw = (nblk + 63) / 64;
-        const int fch = dct_march_chunk(n, nw);
+        const int fch = dct_march_chunk(n, nw, wave_slots > 0 ? wave_slots : 3072);
         dim3 grid((nw + 3) / 4, (n + fch - 1) / fch);
         float2 *p2 = (float2 *)partials;
         const bool ragged = ((w | h) & 7) != 0;

@@ -500,7 +500,8 @@ bool dct_fft_factor(int n, int radix[DCT_FFT_MAX_PASSES], int *npass)
 // leaks into the SMALL difference (~1e-7 of sum |A|: identical frames read 0.5 instead of 0, a static scene with a few
 // changed pixels is off by per cents).  Packing two rows / columns of the SAME plane keeps the leak relative to that
 // plane's own magnitude, and a zero difference stays exactly zero.
-// both sides factor (a transform of up to 4096 points - two buffers - fits 64 KiB of LDS)
+// both sides factor (a transform of up to 4000 points - two buffers of n float2 - stays inside 64 KiB of LDS; 4096 would
+// need all 65536 bytes of the default dynamic-LDS limit and is left to the dense path)
 bool dct_fft_supported(int h, int w)
 {
     int rx[DCT_FFT_MAX_PASSES], np;

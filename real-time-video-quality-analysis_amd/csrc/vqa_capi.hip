@@ -33,6 +33,12 @@ struct resize_tabs {
 
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
+// one cached per-geometry table set and when it was last handed out (least recently used goes first, vqa.h "Memory")
+template <class T> struct cached {
+    T v;
+    uint64_t used = 0;
+};
+
 } // namespace
 
 struct vqa_ctx {
@@ -57,10 +63,13 @@ struct vqa_ctx {
     void *res_host = nullptr; size_t res_host_cap = 0;
     void *qres_host = nullptr; size_t qres_host_cap = 0;
 
-    std::map<std::tuple<int, int, int, int>, resize_tabs> tabs;
-    std::map<std::tuple<int, int, int, int>, fb_resize_tabs> fb_tabs;
-    std::map<int, float *> dct_mats;
-    std::map<int, dct_fft_plan> fft_plans;  // k_dct_fft.hip: twiddle / post-twiddle tables per transform length
+    // per-geometry tables, at most VQA_TABLE_CACHE_GEOMETRIES of each kind (cache_put evicts the least recently used)
+    std::map<std::tuple<int, int, int, int>, cached<resize_tabs>> tabs;
+    std::map<std::tuple<int, int, int, int>, cached<fb_resize_tabs>> fb_tabs;
+    std::map<int, cached<float *>> dct_mats;
+    std::map<int, cached<dct_fft_plan>> fft_plans;  // k_dct_fft.hip: twiddle / post-twiddle tables per transform length
+    uint64_t cache_clock = 0;
+    int dct_wave_slots = 0;                 // wave slots of THIS device for the marching DCT's chunking (set in vqa_create)
     dbuf fb_tmp, fb_blur, fb_img, fb_R, fb_M, fb_flow0, fb_flow1, fb_part;
 
     // pending work
@@ -147,14 +156,23 @@ static int sync_all(vqa_ctx *c)
     return VQA_OK;
 }
 
-static int ensure(vqa_ctx *c, dbuf &b, size_t bytes)
+// lab build: VQA_FAIL_ENSURE_AT=N makes the N-th device reservation of this ctx (scratch buffer or table) report OOM
+static inline bool seam_reservation_fails(vqa_ctx *c)
 {
 #ifdef VQA_TEST_SEAMS
     if (c->seam_fail_at > 0 && ++c->seam_ensure_calls == c->seam_fail_at) {
-        c->last_err = "test seam: scratch reservation #" + std::to_string(c->seam_fail_at) + " made to fail";
-        return VQA_ERR_OOM;
+        c->last_err = "test seam: device reservation #" + std::to_string(c->seam_fail_at) + " made to fail";
+        return true;
     }
+#else
+    (void)c;
 #endif
+    return false;
+}
+
+static int ensure(vqa_ctx *c, dbuf &b, size_t bytes)
+{
+    if (seam_reservation_fails(c)) return VQA_ERR_OOM;
     if (bytes <= b.cap) return VQA_OK;
     // contents are scratch; a pending async user is on one of our own streams
     if (int rc = sync_all(c)) return rc;
@@ -174,6 +192,83 @@ static int ensure_pinned(vqa_ctx *c, void *&p, size_t &cap, size_t bytes)
     p = nullptr; cap = 0;
     HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
     cap = bytes;
+    return VQA_OK;
+}
+
+static void release(dbuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+// The device arrays of ONE table set while it is being built: whatever was reserved is given back unless the whole set
+// made it (commit) - a failure after the first hipMalloc used to drop the earlier pointers.
+struct table_builder {
+    vqa_ctx *c;
+    std::vector<void *> ptrs;
+    bool kept = false;
+    explicit table_builder(vqa_ctx *c_) : c(c_) {}
+    ~table_builder()
+    {
+        if (!kept)
+            for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <class T> int upload(T **out, const void *src, size_t bytes)
+    {
+        if (seam_reservation_fails(c)) return VQA_ERR_OOM;
+        void *d = nullptr;
+        HIPCHK(c, hipMalloc(&d, bytes ? bytes : 1));
+        ptrs.push_back(d);
+        if (bytes) HIPCHK(c, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *out = (T *)d;
+        return VQA_OK;
+    }
+    void commit() { kept = true; }
+};
+
+static void free_table(resize_tabs &t)
+{
+    (void)hipFree(t.xofs); (void)hipFree(t.xa); (void)hipFree(t.yofs); (void)hipFree(t.yb);
+}
+static void free_table(fb_resize_tabs &t)
+{
+    (void)hipFree(t.xofs); (void)hipFree(t.xa); (void)hipFree(t.yofs); (void)hipFree(t.yb);
+    if (t.cols) (void)hipFree(t.cols);
+    if (t.rows) (void)hipFree(t.rows);
+    if (t.sx) (void)hipFree(t.sx);
+    if (t.sy) (void)hipFree(t.sy);
+}
+static void free_table(float *&m) { (void)hipFree(m); }
+static void free_table(dct_fft_plan &P) { (void)hipFree((void *)P.tw); (void)hipFree((void *)P.post); }
+
+// lookup that refreshes the entry's stamp
+template <class Map, class Key, class T> static bool cache_get(vqa_ctx *c, Map &m, const Key &key, T &out)
+{
+    auto it = m.find(key);
+    if (it == m.end()) return false;
+    it->second.used = ++c->cache_clock;
+    out = it->second.v;
+    return true;
+}
+
+// insert; beyond VQA_TABLE_CACHE_GEOMETRIES entries the least recently used set is freed first.  One submit asks for
+// fewer sets of a kind than the bound (<= 6: the Farneback pyramid's), and every set it asked for carries a newer stamp
+// than any other, so an eviction can only hit tables of EARLIER submits - whose kernels have completed (a submit is
+// refused while another is pending); sync_all before the free is the belt to those braces.
+template <class Map, class Key, class T> static int cache_put(vqa_ctx *c, Map &m, const Key &key, const T &v)
+{
+    while (m.size() >= (size_t)VQA_TABLE_CACHE_GEOMETRIES) {
+        auto old = m.begin();
+        for (auto it = m.begin(); it != m.end(); ++it)
+            if (it->second.used < old->second.used) old = it;
+        if (int rc = sync_all(c)) return rc;
+        free_table(old->second.v);
+        m.erase(old);
+    }
+    cached<T> e;
+    e.v = v;
+    e.used = ++c->cache_clock;
+    m[key] = e;
     return VQA_OK;
 }
 
@@ -204,22 +299,20 @@ static void build_axis(int ssize, int dsize, bool is_x, std::vector<int32_t> &of
 static int get_tabs(vqa_ctx *c, int h, int w, int rh, int rw, resize_tabs &out)
 {
     auto key = std::make_tuple(h, w, rh, rw);
-    auto it = c->tabs.find(key);
-    if (it != c->tabs.end()) { out = it->second; return VQA_OK; }
+    if (cache_get(c, c->tabs, key, out)) return VQA_OK;
     resize_tabs t;
     t.mode = (w == 2 * rw && h == 2 * rh) ? 1 : 0;
     std::vector<int32_t> xo, xa, yo, yb;
     build_axis(w, rw, true, xo, xa);
     build_axis(h, rh, false, yo, yb);
-    HIPCHK(c, hipMalloc((void **)&t.xofs, sizeof(int32_t) * rw));
-    HIPCHK(c, hipMalloc((void **)&t.xa, sizeof(int32_t) * 2 * rw));
-    HIPCHK(c, hipMalloc((void **)&t.yofs, sizeof(int32_t) * rh));
-    HIPCHK(c, hipMalloc((void **)&t.yb, sizeof(int32_t) * 2 * rh));
-    HIPCHK(c, hipMemcpy(t.xofs, xo.data(), sizeof(int32_t) * rw, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(t.xa, xa.data(), sizeof(int32_t) * 2 * rw, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(t.yofs, yo.data(), sizeof(int32_t) * rh, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(t.yb, yb.data(), sizeof(int32_t) * 2 * rh, hipMemcpyHostToDevice));
-    c->tabs[key] = t;
+    table_builder tb(c);
+    int rc;
+    if ((rc = tb.upload(&t.xofs, xo.data(), sizeof(int32_t) * rw))) return rc;
+    if ((rc = tb.upload(&t.xa, xa.data(), sizeof(int32_t) * 2 * rw))) return rc;
+    if ((rc = tb.upload(&t.yofs, yo.data(), sizeof(int32_t) * rh))) return rc;
+    if ((rc = tb.upload(&t.yb, yb.data(), sizeof(int32_t) * 2 * rh))) return rc;
+    if ((rc = cache_put(c, c->tabs, key, t))) return rc;
+    tb.commit();
     out = t;
     return VQA_OK;
 }
@@ -227,17 +320,18 @@ static int get_tabs(vqa_ctx *c, int h, int w, int rh, int rw, resize_tabs &out)
 // orthonormal DCT-II matrix C[k][i] = s_k cos(pi (2i+1) k / 2N)  (what cv2.dct applies)
 static int get_dct_matrix(vqa_ctx *c, int n, float **out)
 {
-    auto it = c->dct_mats.find(n);
-    if (it != c->dct_mats.end()) { *out = it->second; return VQA_OK; }
+    if (cache_get(c, c->dct_mats, n, *out)) return VQA_OK;
     std::vector<float> m((size_t)n * n);
     for (int k = 0; k < n; k++) {
         const double s = k == 0 ? std::sqrt(1.0 / n) : std::sqrt(2.0 / n);
         for (int i = 0; i < n; i++) m[(size_t)k * n + i] = (float)(s * std::cos(M_PI * (2.0 * i + 1.0) * k / (2.0 * n)));
     }
     float *d = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d, sizeof(float) * m.size()));
-    HIPCHK(c, hipMemcpy(d, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice));
-    c->dct_mats[n] = d;
+    table_builder tb(c);
+    int rc;
+    if ((rc = tb.upload(&d, m.data(), sizeof(float) * m.size()))) return rc;
+    if ((rc = cache_put(c, c->dct_mats, n, d))) return rc;
+    tb.commit();
     *out = d;
     return VQA_OK;
 }
@@ -245,8 +339,7 @@ static int get_dct_matrix(vqa_ctx *c, int n, float **out)
 // k_dct_fft.hip's plan for length n (tables formed in double, rounded once); VQA_ERR_UNSUPPORTED if n does not factor
 static int get_fft_plan(vqa_ctx *c, int n, dct_fft_plan *out)
 {
-    auto it = c->fft_plans.find(n);
-    if (it != c->fft_plans.end()) { *out = it->second; return VQA_OK; }
+    if (cache_get(c, c->fft_plans, n, *out)) return VQA_OK;
     dct_fft_plan P;
     memset(&P, 0, sizeof P);
     P.n = n;
@@ -254,7 +347,7 @@ static int get_fft_plan(vqa_ctx *c, int n, dct_fft_plan *out)
     for (int p = 0, Ns = 1; p < P.npass; Ns *= P.radix[p], p++) {
         P.m[p] = n / P.radix[p];
         P.tstep[p] = n / (Ns * P.radix[p]);
-        // j / Ns = mulhi(j, ceil(2^32 / Ns)), exact while j * Ns < 2^32 (n <= 4096); the first pass (Ns = 1) does not use it
+        // j / Ns = mulhi(j, ceil(2^32 / Ns)), exact while j * Ns < 2^32 (n <= 4000); the first pass (Ns = 1) does not use it
         P.ns_magic[p] = Ns == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)Ns - 1) / (uint64_t)Ns);
     }
     std::vector<float2> tw((size_t)n), post((size_t)n);
@@ -265,12 +358,13 @@ static int get_fft_plan(vqa_ctx *c, int n, dct_fft_plan *out)
         post[m] = make_float2((float)(s * std::cos(b)), (float)(s * std::sin(b)));
     }
     float2 *dtw = nullptr, *dpost = nullptr;
-    HIPCHK(c, hipMalloc((void **)&dtw, sizeof(float2) * n));
-    HIPCHK(c, hipMalloc((void **)&dpost, sizeof(float2) * n));
-    HIPCHK(c, hipMemcpy(dtw, tw.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dpost, post.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    table_builder tb(c);
+    int rc;
+    if ((rc = tb.upload(&dtw, tw.data(), sizeof(float2) * n))) return rc;
+    if ((rc = tb.upload(&dpost, post.data(), sizeof(float2) * n))) return rc;
     P.tw = dtw; P.post = dpost;
-    c->fft_plans[n] = P;
+    if ((rc = cache_put(c, c->fft_plans, n, P))) return rc;
+    tb.commit();
     *out = P;
     return VQA_OK;
 }
@@ -342,22 +436,19 @@ static void fb_build_axis(int ssize, int dsize, bool is_x, std::vector<int32_t> 
 static int get_fb_tabs(vqa_ctx *c, int sh, int sw, int dh, int dw, fb_resize_tabs &out)
 {
     auto key = std::make_tuple(sh, sw, dh, dw);
-    auto it = c->fb_tabs.find(key);
-    if (it != c->fb_tabs.end()) { out = it->second; return VQA_OK; }
+    if (cache_get(c, c->fb_tabs, key, out)) return VQA_OK;
     fb_resize_tabs t;
     t.mode = (sw == 2 * dw && sh == 2 * dh) ? 1 : 0;
     std::vector<int32_t> xo, yo;
     std::vector<float> xa, yb;
     fb_build_axis(sw, dw, true, xo, xa);
     fb_build_axis(sh, dh, false, yo, yb);
-    HIPCHK(c, hipMalloc((void **)&t.xofs, sizeof(int32_t) * dw));
-    HIPCHK(c, hipMalloc((void **)&t.xa, sizeof(float) * 2 * dw));
-    HIPCHK(c, hipMalloc((void **)&t.yofs, sizeof(int32_t) * dh));
-    HIPCHK(c, hipMalloc((void **)&t.yb, sizeof(float) * 2 * dh));
-    HIPCHK(c, hipMemcpy(t.xofs, xo.data(), sizeof(int32_t) * dw, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(t.xa, xa.data(), sizeof(float) * 2 * dw, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(t.yofs, yo.data(), sizeof(int32_t) * dh, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(t.yb, yb.data(), sizeof(float) * 2 * dh, hipMemcpyHostToDevice));
+    table_builder tb(c);
+    int rc;
+    if ((rc = tb.upload(&t.xofs, xo.data(), sizeof(int32_t) * dw))) return rc;
+    if ((rc = tb.upload(&t.xa, xa.data(), sizeof(float) * 2 * dw))) return rc;
+    if ((rc = tb.upload(&t.yofs, yo.data(), sizeof(int32_t) * dh))) return rc;
+    if ((rc = tb.upload(&t.yb, yb.data(), sizeof(float) * 2 * dh))) return rc;
     if (dw <= sw && dh <= sh) {
         // the samples of each level column / row as the fused level kernel wants them, and their extent per tile
         std::vector<int32_t> sx(2 * (size_t)dw), sy(2 * (size_t)dh);
@@ -385,10 +476,8 @@ static int get_fb_tabs(vqa_ctx *c, int sh, int sw, int dh, int dw, fb_resize_tab
         };
         t.span_x32 = span(sx, dw, 32); t.span_y8 = span(sy, dh, 8); t.span_y32 = span(sy, dh, 32);
         if (t.span_x32 > 0 && t.span_y8 > 0 && t.span_y32 > 0) {
-            HIPCHK(c, hipMalloc((void **)&t.sx, sizeof(int32_t) * sx.size()));
-            HIPCHK(c, hipMalloc((void **)&t.sy, sizeof(int32_t) * sy.size()));
-            HIPCHK(c, hipMemcpy(t.sx, sx.data(), sizeof(int32_t) * sx.size(), hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(t.sy, sy.data(), sizeof(int32_t) * sy.size(), hipMemcpyHostToDevice));
+            if ((rc = tb.upload(&t.sx, sx.data(), sizeof(int32_t) * sx.size()))) return rc;
+            if ((rc = tb.upload(&t.sy, sy.data(), sizeof(int32_t) * sy.size()))) return rc;
         }
     }
     if (t.mode == 0 && (dw < sw || dh < sh)) {
@@ -404,12 +493,11 @@ static int get_fb_tabs(vqa_ctx *c, int sh, int sw, int dh, int dw, fb_resize_tab
         for (int x = 0; x < sw; x++) if (cm[x]) cs.push_back(x);
         for (int y = 0; y < sh; y++) if (rm[y]) rs.push_back(y);
         t.nc = (int)cs.size(); t.nr = (int)rs.size();
-        HIPCHK(c, hipMalloc((void **)&t.cols, sizeof(int32_t) * t.nc));
-        HIPCHK(c, hipMalloc((void **)&t.rows, sizeof(int32_t) * t.nr));
-        HIPCHK(c, hipMemcpy(t.cols, cs.data(), sizeof(int32_t) * t.nc, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(t.rows, rs.data(), sizeof(int32_t) * t.nr, hipMemcpyHostToDevice));
+        if ((rc = tb.upload(&t.cols, cs.data(), sizeof(int32_t) * t.nc))) return rc;
+        if ((rc = tb.upload(&t.rows, rs.data(), sizeof(int32_t) * t.nr))) return rc;
     }
-    c->fb_tabs[key] = t;
+    if ((rc = cache_put(c, c->fb_tabs, key, t))) return rc;
+    tb.commit();
     out = t;
     return VQA_OK;
 }
@@ -462,25 +550,49 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
         lwk[k] = (int)std::lrint(w * scale);
         lhk[k] = (int)std::lrint(h * scale);
     }
-    int mc = (int)((12ull << 30) / ((two_kernel ? 72 : 59) * P));
+    // pairs per chunk: ~12 GiB of scratch, and never more than 80 % of what the device can give right now (what this ctx
+    // already holds for Farneback counts as available: ensure() re-uses or replaces it).  If a reservation still fails -
+    // another context or process took the memory in between - the chunk is halved and everything re-reserved, down to
+    // one pair, before the submit reports VQA_ERR_OOM.
+    dbuf *const fb_bufs[] = {&c->fb_tmp, &c->fb_blur, &c->fb_img, &c->fb_R, &c->fb_M, &c->fb_flow0, &c->fb_flow1, &c->fb_part};
+    const size_t per_pair = (size_t)(two_kernel ? 72 : 59) * P;
+    size_t budget = 12ull << 30;
+    {
+        size_t free_b = 0, total_b = 0, held = 0;
+        for (dbuf *b : fb_bufs) held += b->cap;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t avail = (size_t)((double)(free_b + held) * 0.8);
+            if (avail < budget) budget = avail;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    int mc = (int)(budget / per_pair);
     mc = mc < 1 ? 1 : (mc > n ? n : mc);
-    for (k = levels; k >= 0; k--) { Roff[k] = Rtot; Rtot += (size_t)5 * lhk[k] * lwk[k] * (mc + 1); }
     const bool piped = c->opt_overlap && !two_kernel && !three_kernel;
     int rc;
-    if ((rc = ensure(c, c->fb_tmp, sizeof(float) * P * (mc + 1)))) return rc;
-    if ((rc = ensure(c, c->fb_blur, sizeof(float) * P * (mc + 1)))) return rc;
-    if ((rc = ensure(c, c->fb_img, sizeof(float) * P * (mc + 1)))) return rc;
-    if ((rc = ensure(c, c->fb_R, sizeof(float) * Rtot))) return rc;
-    if (two_kernel && (rc = ensure(c, c->fb_M, sizeof(float) * 5 * P * mc))) return rc;
-    if ((rc = ensure(c, c->fb_flow0, sizeof(float) * 2 * P * mc))) return rc;
-    if ((rc = ensure(c, c->fb_flow1, sizeof(float) * 2 * P * mc))) return rc;
-    {
+    for (;;) {
+        Rtot = 0;
+        for (k = levels; k >= 0; k--) { Roff[k] = Rtot; Rtot += (size_t)5 * lhk[k] * lwk[k] * (mc + 1); }
         int nb = fb_iter_max_blocks(h, w); // partial |flow| sums per pair: one per workgroup of the last iteration
 #ifdef VQA_AB_VARIANTS
         if (fb_mag_blocks() > nb) nb = fb_mag_blocks();
 #endif
-        if ((rc = ensure(c, c->fb_part, sizeof(double) * (size_t)nb * mc))) return rc;
+        rc = ensure(c, c->fb_tmp, sizeof(float) * P * (mc + 1));
+        if (!rc) rc = ensure(c, c->fb_blur, sizeof(float) * P * (mc + 1));
+        if (!rc) rc = ensure(c, c->fb_img, sizeof(float) * P * (mc + 1));
+        if (!rc) rc = ensure(c, c->fb_R, sizeof(float) * Rtot);
+        if (!rc && two_kernel) rc = ensure(c, c->fb_M, sizeof(float) * 5 * P * mc);
+        if (!rc) rc = ensure(c, c->fb_flow0, sizeof(float) * 2 * P * mc);
+        if (!rc) rc = ensure(c, c->fb_flow1, sizeof(float) * 2 * P * mc);
+        if (!rc) rc = ensure(c, c->fb_part, sizeof(double) * (size_t)nb * mc);
+        if (rc != VQA_ERR_OOM || mc == 1 || c->last_err.compare(0, 10, "test seam:") == 0) break; // (an injected failure is not retried)
+        (void)hipGetLastError();
+        if (int rs = sync_all(c)) return rs;
+        for (dbuf *b : fb_bufs) release(*b);
+        mc = (mc + 1) / 2;
     }
+    if (rc) return rc;
     float *tmp = (float *)c->fb_tmp.p, *blur = (float *)c->fb_blur.p, *img = (float *)c->fb_img.p;
     float *Rall = (float *)c->fb_R.p;
 #ifdef VQA_AB_VARIANTS
@@ -631,6 +743,7 @@ int vqa_create(int device, vqa_ctx **out)
         delete c;
         return VQA_ERR_HIP;
     }
+    c->dct_wave_slots = dct8_wave_slots(); // (the device is current: hipSetDevice above)
     // the one environment variable the shipped library reads (documented in vqa.h): the initial VQA_OPT_OVERLAP
     if (const char *e = getenv("VQA_OVERLAP")) c->opt_overlap = atoi(e) != 0;
 #ifdef VQA_TEST_SEAMS
@@ -674,33 +787,47 @@ int vqa_build_flavour(void)
     return f;
 }
 
+// every grow-only buffer, the result staging and every cached table of an idle ctx (vqa_trim, vqa_destroy)
+static void release_scratch(vqa_ctx *c)
+{
+    dbuf *bufs[] = {&c->gray_full, &c->planeA, &c->planeB, &c->state, &c->res_dev, &c->partials, &c->tile_flags,
+                    &c->dirty0, &c->dirty1, &c->again_dev, &c->stage_frames, &c->stage_prev, &c->dct_scratch,
+                    &c->dct_pe, &c->dct_pt, &c->qres_dev, &c->qpartials, &c->qstage_ref, &c->qstage_dist,
+                    &c->fb_tmp, &c->fb_blur, &c->fb_img, &c->fb_R, &c->fb_M, &c->fb_flow0, &c->fb_flow1, &c->fb_part};
+    for (dbuf *b : bufs) release(*b);
+    for (auto &kv : c->tabs) free_table(kv.second.v);
+    for (auto &kv : c->fb_tabs) free_table(kv.second.v);
+    for (auto &kv : c->dct_mats) free_table(kv.second.v);
+    for (auto &kv : c->fft_plans) free_table(kv.second.v);
+    c->tabs.clear(); c->fb_tabs.clear(); c->dct_mats.clear(); c->fft_plans.clear();
+    if (c->res_host) (void)hipHostFree(c->res_host);
+    if (c->qres_host) (void)hipHostFree(c->qres_host);
+    c->res_host = c->qres_host = nullptr;
+    c->res_host_cap = c->qres_host_cap = 0;
+    // the planes vqa_debug_read_plane would read are gone
+    c->last_n = 0; c->last_has_full = c->last_has_state = c->last_has_planes = false;
+}
+
+int vqa_trim(vqa_ctx *c)
+{
+    if (!c) return VQA_ERR_INVALID;
+    if (c->pend_c || c->pend_q) return VQA_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = sync_all(c)) return rc;
+    prof_collect(c);
+    release_scratch(c);
+    (void)hipGetLastError();
+    return VQA_OK;
+}
+
 int vqa_destroy(vqa_ctx *c)
 {
     if (!c) return VQA_ERR_INVALID;
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
-    dbuf *bufs[] = {&c->gray_full, &c->planeA, &c->planeB, &c->state, &c->res_dev, &c->partials, &c->tile_flags,
-                    &c->dirty0, &c->dirty1, &c->again_dev, &c->stage_frames, &c->stage_prev, &c->dct_scratch,
-                    &c->dct_pe, &c->dct_pt, &c->qres_dev, &c->qpartials, &c->qstage_ref, &c->qstage_dist,
-                    &c->fb_tmp, &c->fb_blur, &c->fb_img, &c->fb_R, &c->fb_M, &c->fb_flow0, &c->fb_flow1, &c->fb_part};
-    for (dbuf *b : bufs)
-        if (b->p) (void)hipFree(b->p);
-    for (auto &kv : c->tabs) {
-        (void)hipFree(kv.second.xofs); (void)hipFree(kv.second.xa); (void)hipFree(kv.second.yofs); (void)hipFree(kv.second.yb);
-    }
-    for (auto &kv : c->fb_tabs) {
-        (void)hipFree(kv.second.xofs); (void)hipFree(kv.second.xa); (void)hipFree(kv.second.yofs); (void)hipFree(kv.second.yb);
-        if (kv.second.cols) (void)hipFree(kv.second.cols);
-        if (kv.second.rows) (void)hipFree(kv.second.rows);
-        if (kv.second.sx) (void)hipFree(kv.second.sx);
-        if (kv.second.sy) (void)hipFree(kv.second.sy);
-    }
-    for (auto &kv : c->dct_mats) (void)hipFree(kv.second);
-    for (auto &kv : c->fft_plans) { (void)hipFree((void *)kv.second.tw); (void)hipFree((void *)kv.second.post); }
+    release_scratch(c);
     for (auto &t : c->ev_open) { (void)hipEventDestroy(std::get<1>(t)); (void)hipEventDestroy(std::get<2>(t)); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->res_host) (void)hipHostFree(c->res_host);
-    if (c->qres_host) (void)hipHostFree(c->qres_host);
     for (int i = 0; i < 3; i++) {
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -726,6 +853,19 @@ int vqa_free_pinned(vqa_ctx *c, void *p)
 {
     if (!c || !p) return VQA_ERR_INVALID;
     HIPCHK(c, hipHostFree(p));
+    return VQA_OK;
+}
+int vqa_host_is_pinned(vqa_ctx *c, const void *p, int *out)
+{
+    if (!c || !p || !out) return VQA_ERR_INVALID;
+    *out = 0;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { // ordinary host memory: HIP has never heard of it
+        (void)hipGetLastError();
+        return VQA_OK;
+    }
+    *out = a.type == hipMemoryTypeHost ? 1 : 0;
     return VQA_OK;
 }
 int vqa_alloc_device(vqa_ctx *c, size_t bytes, void **out)
@@ -941,7 +1081,7 @@ static int complexity_submit_body(vqa_ctx *c, const uint8_t *frames, const uint8
             rc = ensure(c, c->partials, sizeof(double) * 2 * (size_t)pb * n);
             if (rc) return rc;
             prof_scope ps_(c, VQA_K_DCT8);
-            launch_dct8(st, pA, pp, plane_stride, n, ph, pw, want_dct, want_t, has_prev0, (double *)c->partials.p, res);
+            launch_dct8(st, pA, pp, plane_stride, n, ph, pw, want_dct, want_t, has_prev0, (double *)c->partials.p, res, c->dct_wave_slots);
         } else {
             if (dct_fft_supported(ph, pw)) {
                 // both sides factor into 2, 3, 5: FFT-based row / column passes (k_dct_fft.hip)

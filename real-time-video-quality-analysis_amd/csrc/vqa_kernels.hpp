@@ -45,8 +45,11 @@ void launch_orb64(hipStream_t st, const uint8_t *bgr, int n, int h, int w, int64
 
 // k_dct8.hip
 int dct8_blocks_per_frame(int h, int w);
+// wave slots of the CURRENT device for the marching kernel (CUs x resident workgroups x 4): queried once per ctx in
+// vqa_create and handed to every launch - no process-wide cache of a per-device quantity
+int dct8_wave_slots();
 void launch_dct8(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,
-                 bool energy, bool temporal, bool first_has_prev, double *partials, vqa_frame_metrics *res);
+                 bool energy, bool temporal, bool first_has_prev, double *partials, vqa_frame_metrics *res, int wave_slots);
 
 // k_dct_full.hip
 void launch_dct_full(hipStream_t st, const uint8_t *planes, int pitch, int64_t plane_stride, int n, int h, int w,

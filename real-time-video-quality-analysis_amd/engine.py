@@ -148,8 +148,34 @@ class Engine:
         raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))
         return raw[:nbytes].view(dtype).reshape(shape)
 
+    def free_pinned(self, arr):
+        """Give back an array alloc_pinned returned (it must not be used afterwards)."""
+        p = arr.ctypes.data if hasattr(arr, "ctypes") else int(arr)
+        if p in getattr(self, "_pinned", []):
+            self._pinned.remove(p)
+            N.check(self.lib.vqa_free_pinned(self.ctx, p), "vqa_free_pinned", self.ctx)
+
+    def is_pinned(self, arr):
+        """True if the array's memory is page-locked and known to HIP (alloc_pinned, torch pin_memory, hipHostRegister):
+        a submit / h2d from it is an asynchronous DMA; pageable memory is staged through a pinned ring (stream.py)."""
+        if getattr(arr, "nbytes", 0) == 0:
+            return False
+        out = C.c_int(0)
+        N.check(self.lib.vqa_host_is_pinned(self.ctx, arr.ctypes.data, C.byref(out)), "vqa_host_is_pinned", self.ctx)
+        return bool(out.value)
+
+    def h2d_async(self, dst_ptr, src_ptr, nbytes):
+        """Enqueue a host-to-device copy on the engine's stream (a true DMA when the source is pinned)."""
+        if nbytes:
+            N.check(self.lib.vqa_copy_h2d(self.ctx, int(dst_ptr), int(src_ptr), int(nbytes)), "vqa_copy_h2d", self.ctx)
+
     def sync(self):
         N.check(self.lib.vqa_sync(self.ctx), "vqa_sync", self.ctx)
+
+    def trim(self):
+        """vqa_trim: give back every scratch buffer, the result staging and every cached table of this (idle) engine.
+        The next submit re-grows what it needs; results are unaffected."""
+        N.check(self.lib.vqa_trim(self.ctx), "vqa_trim", self.ctx)
 
     # ---- options (include/vqa.h: none of them changes a result) --------------
     def set_option(self, option, value):

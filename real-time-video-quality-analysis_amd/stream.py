@@ -1,0 +1,431 @@
+"""One pass of a clip through the engine: every byte crosses PCIe once, every frame is measured once.
+
+This is the host side of the reference's hot path as its callers drive it:
+
+    process_video_and_extract_metrics   video_processing.py:216 (run_ffmpeg_metrics) + :242
+                                        (calculate_average_scene_complexity) on the SAME encoded stream
+    run_ffmpeg_metrics                  video_processing.py:270-297   (quality only)
+    calculate_average_scene_complexity  complexity_metrics.py:246-310 (complexity only)
+
+The reference decodes the encoded stream three times and pickles every frame into a process pool seven times
+(SURVEY.md 3.2); here a clip is cut into chunks, a chunk is brought to the device ONCE and both the quality kernels
+(all frames) and the complexity kernels (every frame_interval-th frame, a strided view of the same device bytes)
+read it there.  Where the frames come from decides how they travel:
+
+    device    DeviceFrames (torch tensor, vqa_alloc_device): views, nothing moves
+    pinned    page-locked host memory (Engine.alloc_pinned, torch pin_memory - north_star's "decoded frames in
+              pinned buffers"): vqa_copy_h2d straight from the caller's memory, an asynchronous DMA
+    pageable  ordinary NumPy arrays / np.load(mmap_mode="r"): copier threads move chunk k+1 into a slot of a
+              pinned ring (np.copyto releases the GIL) while chunk k crosses PCIe and chunk k-1 is on the GPU
+
+Chunks alternate between two engines (= two HIP streams with their own scratch) on the device, so the copy of one
+chunk overlaps the kernels of the other and the host-side float tails (tails.py) of a finished chunk run while
+the GPU works on the next.  Nothing here computes a metric: pointers in, records out.
+"""
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _native as N
+from . import tails
+from .engine import DeviceBuffer, DeviceFrames, Engine
+from .pooling import shard_range
+
+CHUNK_BYTES_MAX = 1 << 30     # per chunk and stream on the device / in a ring slot (a chunk is at most batch_size frames)
+STAGE_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))  # copier threads of the pinned ring
+
+KINDS = ("motion", "dct", "hist", "edge", "orb", "color")
+MASK = {"dct": N.M_DCT, "temporal": N.M_TEMPORAL_DCT, "hist": N.M_GRAY_HIST, "color": N.M_COLOR_HIST,
+        "edge": N.M_EDGE, "motion": N.M_MOTION, "orb": N.M_ORB}
+
+_engines = {}
+_second = {}
+_staging = {}
+_lock = threading.RLock()
+
+
+def get_engine(device=None):
+    """One Engine per (process, device).  Default device: VQA_DEVICE, else LOCAL_RANK, else 0."""
+    if device is None:
+        device = int(os.environ.get("VQA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _lock:
+        if device not in _engines:
+            _engines[device] = Engine(device)
+        return _engines[device]
+
+
+def get_engine_pair(device=None):
+    """Two engines (= two HIP streams with their own scratch) on one device: while chunk k's kernels run on one,
+    chunk k+1 crosses PCIe on the other."""
+    first = get_engine(device)
+    with _lock:
+        if first.device not in _second:
+            _second[first.device] = Engine(first.device)
+        return first, _second[first.device]
+
+
+class _Staging:
+    """What a device's passes keep between calls so that a steady stream of clips allocates nothing: the pinned ring
+    and the per-lane device buffers (release_buffers() gives them back).  Owned by the process's default engine of the
+    device, so a caller's short-lived engine can run a pass without taking the buffers with it.  Like the engines
+    themselves this is per process and device and NOT thread-safe: one pass at a time per device."""
+
+    def __init__(self, engine):
+        self.engine = engine          # owner of the pinned slots and lane buffers
+        self.slots = []               # pinned uint8 arrays, all of slot_bytes
+        self.slot_bytes = 0
+        self.dev = {}                 # (lane, name) -> DeviceBuffer
+        self.pool = None
+
+    def ring(self, count, nbytes):
+        if nbytes > self.slot_bytes or len(self.slots) < count:
+            for a in self.slots:
+                self.engine.free_pinned(a)
+            self.slots = []
+            self.slot_bytes = max(nbytes, self.slot_bytes)
+            self.slots = [self.engine.alloc_pinned((self.slot_bytes,)) for _ in range(count)]
+        return self.slots[:count]
+
+    def device_buffer(self, lane, name, nbytes):
+        b = self.dev.get((lane, name))
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()  # (no pass is running: every chunk of the previous one was waited for)
+            b = self.dev[(lane, name)] = DeviceBuffer(self.engine, nbytes)
+        return b
+
+    def copiers(self):
+        if self.pool is None:
+            self.pool = ThreadPoolExecutor(max_workers=STAGE_THREADS, thread_name_prefix="vqa-stage")
+        return self.pool
+
+    def release(self):
+        for a in self.slots:
+            self.engine.free_pinned(a)
+        self.slots, self.slot_bytes = [], 0
+        for b in self.dev.values():
+            b.free()
+        self.dev = {}
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
+
+
+def _staging_of(engine):
+    with _lock:
+        st = _staging.get(engine.device)
+        if st is None:
+            st = _staging[engine.device] = _Staging(get_engine(engine.device))
+        return st
+
+
+def release_buffers(device=None):
+    """Give back what the passes keep between calls on `device` (all devices when None): the pinned ring, the lane
+    buffers on the device and - vqa_trim - every engine's scratch and cached tables.  The reference holds nothing
+    between calls (a process pool per call, complexity_metrics.py:143-147); the next call re-grows what it needs."""
+    with _lock:
+        devs = [device] if device is not None else sorted(set(_staging) | set(_engines))
+        for d in devs:
+            if d in _staging:
+                _staging.pop(d).release()
+            for table in (_engines, _second):
+                if d in table:
+                    table[d].trim()
+
+
+# ---------------------------------------------------------------------------
+# sources
+# ---------------------------------------------------------------------------
+class _Source:
+    """n frames of `fb` bytes each: a device-resident clip or a host array whose first axis is the frame."""
+
+    def __init__(self, frames, engine):
+        self.frames = frames
+        if isinstance(frames, DeviceFrames):
+            self.kind, self.n = "device", frames.n
+            self.fb = frames.h * frames.w * frames.channels
+            return
+        self.n = frames.shape[0]
+        self.fb = int(np.prod(frames.shape[1:], dtype=np.int64)) if frames.ndim > 1 else 1
+        compact = self.n == 0 or (frames[0].flags.c_contiguous and (self.n == 1 or frames.strides[0] >= self.fb))
+        # padded rows / a region of interest inside larger frames: the ring compacts them on the way
+        self.kind = "pinned" if (compact and self.n and engine.is_pinned(frames)) else "pageable"
+
+    def view(self, start, count, step=1):
+        return self.frames[start:start + (count - 1) * step + 1:step]
+
+
+class _Copy:
+    """frames `view` of a source -> frame slots [slot, slot + len(view)) of a chunk buffer"""
+
+    def __init__(self, slot, view):
+        self.slot, self.view = slot, view
+
+
+def _fill_slot(pool, ring_frames, copies):
+    """pageable -> pinned: every copy split over the copier threads by frames; returns the futures"""
+    futs = []
+    for cp in copies:
+        n = len(cp.view)
+        parts = min(STAGE_THREADS, n)
+        for t in range(parts):
+            a, b = n * t // parts, n * (t + 1) // parts
+            dst = ring_frames[cp.slot + a:cp.slot + b].reshape((b - a,) + cp.view.shape[1:])  # (the ring is contiguous: a view)
+            futs.append(pool.submit(np.copyto, dst, cp.view[a:b]))
+    return futs
+
+
+def _upload(engine, dev_ptr, fb, copies, ring_frames=None):
+    """enqueue the H2D copies of a chunk: from the ring slot (contiguous spans) or straight from pinned user memory"""
+    for cp in copies:
+        n = len(cp.view)
+        if ring_frames is not None:
+            engine.h2d_async(dev_ptr + cp.slot * fb, ring_frames[cp.slot:].ctypes.data, n * fb)
+        elif n == 1 or cp.view.strides[0] == fb:
+            engine.h2d_async(dev_ptr + cp.slot * fb, cp.view.ctypes.data, n * fb)
+        else:  # every k-th frame of a pinned clip: only the selected frames cross PCIe
+            base, step = cp.view.ctypes.data, cp.view.strides[0]
+            for i in range(n):
+                engine.h2d_async(dev_ptr + (cp.slot + i) * fb, base + i * step, fb)
+
+
+# ---------------------------------------------------------------------------
+# the pass
+# ---------------------------------------------------------------------------
+def selected_indices(num_frames, frame_interval):
+    """0-based indices read_frame_pairs keeps: 1-based count % interval == 0 (complexity_metrics.py:103-104)."""
+    return np.arange(frame_interval - 1, num_frames, frame_interval)
+
+
+class Complexity:
+    """What the complexity half of a pass measures (arguments of calculate_average_scene_complexity)."""
+
+    def __init__(self, resize, frame_interval=10, mask=N.M_ALL, dct_mode=N.DCT_AUTO, motion_mode=N.MOTION_SAD, shard=None):
+        self.resize, self.interval, self.mask = resize, int(frame_interval), mask
+        self.dct_mode, self.motion_mode, self.shard = dct_mode, motion_mode, shard
+
+
+class Quality:
+    """What the quality half compares: `planes` of every frame (engine.bgr_planes / yuv420p_planes ...)."""
+
+    def __init__(self, planes, ssim_mode=N.SSIM_GAUSS):
+        self.planes, self.ssim_mode = planes, ssim_mode
+
+
+def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=None, on_quality=None):
+    """One pass over a clip.
+
+    dist        the stream both halves read: [N,H,W,3] uint8 BGR (host array, memmap or DeviceFrames); for a
+                quality-only pass any [N, frame_bytes] layout the planes describe
+    ref         the reference stream of the quality half (same layout), or None
+    quality     Quality or None;  complexity  Complexity or None
+    on_quality  optional callback(first_frame, sse [m,p], ssim [m,p]) per finished chunk, in frame order (stats
+                lines are formatted while the GPU works on the next chunk)
+    -> (sse [n,p] uint64, ssim [n,p] float64) or None, series dict or None.
+    series: kind -> list in the reference's sample order (motion/dct/hist/edge/orb/color: T-1 samples, temporal:
+    T-2, complexity_metrics.py:268-290, :533-537) and "range" = the shard's place in the whole series."""
+    want_q, want_c = quality is not None, complexity is not None
+    on_device = isinstance(dist, DeviceFrames)
+    n = dist.n if on_device else dist.shape[0]
+    if want_c and (dist.channels != 3 if on_device else (dist.ndim != 4 or dist.shape[3] != 3)):
+        raise ValueError("frames must be uint8 [N,H,W,3] packed BGR")
+    series = None
+    if want_c:
+        cx = complexity
+        idx = selected_indices(n, cx.interval)
+        T1 = max(len(idx) - 1, 0)
+        lo, hi = shard_range(T1, *cx.shard) if cx.shard is not None else (0, T1)
+        if cx.shard is not None and want_q:
+            raise ValueError("a sharded pass measures complexity only")
+        series = {k: [] for k in KINDS + ("temporal",)}
+        series["range"] = (lo, hi)
+        if hi <= lo:
+            want_c = False  # unopenable / too short: empty series, as the reference's empty pair list (:95-97)
+    if not want_q and not want_c:
+        return None, series  # (no engine is created for a clip with nothing to measure)
+    if n == 0:
+        e = np.zeros((0, len(quality.planes)))
+        return (e.astype(np.uint64), e), series
+    first = engine or get_engine(_device_of(dist))
+    src = _Source(dist, first)
+    rsrc = _Source(ref, first) if want_q else None
+    if want_q and (rsrc.n != src.n or rsrc.fb != src.fb or (rsrc.kind == "device") != (src.kind == "device")):
+        raise ValueError("reference and distorted streams must have the same frame count, layout and residence")
+
+    fb = src.fb
+    # ---- chunks: (a, b) dense source range (quality present) or (j0, j1) sample range (complexity only)
+    per_frame = fb * (2 if want_q else 1)
+    cap = max(1, min(int(batch_size), CHUNK_BYTES_MAX // max(per_frame, 1) if src.kind != "device" else int(batch_size)))
+    chunks = [(a, min(a + cap, n)) for a in range(0, n, cap)] if want_q else [(j, min(j + cap, hi)) for j in range(lo, hi, cap)]
+    # ---- lanes
+    farneback = want_c and (complexity.mask & N.M_MOTION) and complexity.motion_mode == N.MOTION_FARNEBACK
+    if engine is not None or len(chunks) <= 1 or farneback:
+        lanes = [first]  # (Farneback keeps GiB-sized scratch per context and fills the chip on its own: one context)
+    else:
+        lanes = list(get_engine_pair(first.device))
+    host = src.kind != "device"
+    staged = host and (src.kind == "pageable" or (want_q and rsrc.kind == "pageable"))
+    st = _staging_of(first) if host else None
+    params = first.make_params(resize=complexity.resize, dct_mode=complexity.dct_mode,
+                               motion_mode=complexity.motion_mode) if want_c else None
+    if host:
+        for ln in range(len(lanes)):  # lane buffers: slot 0 of the distorted stream is the halo (the frame before the chunk's first sample)
+            st.device_buffer(ln, "dist", (cap + 1) * fb)
+            if want_q:
+                st.device_buffer(ln, "ref", cap * fb)
+    ring = st.ring(len(lanes) + 1, (cap + 1) * fb + (cap * fb if want_q else 0)) if staged else None
+    free_slots = list(range(len(ring))) if staged else None
+
+    def plan(k):
+        """the chunk's host copies and where its samples sit: -> dict"""
+        a, b = chunks[k]
+        p = dict(k=k, copies=[], rcopies=[])
+        if want_q:
+            p.update(q0=a, qn=b - a)
+            if want_c:
+                # samples whose frame lies in [a, b): sample j measures selected frame idx[1 + j]
+                iv = complexity.interval
+                j0 = max(lo, int(np.searchsorted(idx, a)) - 1, 0)
+                j1 = max(j0, min(hi, int(np.searchsorted(idx, b)) - 1))
+                p.update(j0=j0, j1=j1)
+                if j1 > j0:
+                    prev = int(idx[j0])
+                    p.update(first=int(idx[1 + j0]) - a, step=iv, prev_slot=(prev - a) if prev >= a else -1)
+                    if host and prev < a:
+                        p["copies"].append(_Copy(0, src.view(prev, 1)))
+            if host:
+                p["copies"].append(_Copy(1, src.view(a, b - a)))
+                p["rcopies"].append(_Copy(0, rsrc.view(a, b - a)))
+        else:
+            j0, j1 = a, b
+            iv = complexity.interval
+            p.update(j0=j0, j1=j1, first=0, step=1, prev_slot=-1)
+            if host:
+                if iv == 1:  # the frame before the first sample and the samples are one contiguous range
+                    p["copies"].append(_Copy(0, src.view(int(idx[j0]), j1 - j0 + 1)))
+                else:
+                    p["copies"].append(_Copy(0, src.view(int(idx[j0]), 1)))
+                    p["copies"].append(_Copy(1, src.view(int(idx[1 + j0]), j1 - j0, iv)))
+        return p
+
+    def start_fill(p):
+        if not staged:
+            return
+        slot = free_slots.pop()
+        blk = ring[slot]
+        p["slot"] = slot
+        p["ring_d"] = blk[:(cap + 1) * fb].reshape(cap + 1, fb)
+        futs = _fill_slot(st.copiers(), p["ring_d"], p["copies"])
+        if want_q:
+            p["ring_r"] = blk[(cap + 1) * fb:(cap + 1) * fb + cap * fb].reshape(cap, fb)
+            futs += _fill_slot(st.copiers(), p["ring_r"], p["rcopies"])
+        p["fill"] = futs
+
+    def submit(p, eng):
+        if host:
+            for f in p.get("fill", ()):
+                f.result()
+            ln = p["k"] % len(lanes)
+            dd = st.device_buffer(ln, "dist", (cap + 1) * fb)
+            _upload(eng, dd.ptr, fb, p["copies"], p.get("ring_d"))
+            if want_q:
+                dr = st.device_buffer(ln, "ref", cap * fb)
+                _upload(eng, dr.ptr, fb, p["rcopies"], p.get("ring_r"))
+        p["has_q"] = p["has_c"] = False
+        if want_q:
+            if host:
+                qr = DeviceFrames(dr.ptr, p["qn"], 1, fb, frame_stride=fb, row_stride=fb, owner=dr, channels=1)
+                qd = DeviceFrames(dd.ptr + fb, p["qn"], 1, fb, frame_stride=fb, row_stride=fb, owner=dd, channels=1)
+            else:
+                qr, qd = ref.slice(p["q0"], p["q0"] + p["qn"]), dist.slice(p["q0"], p["q0"] + p["qn"])
+            eng.quality_submit(qr, qd, quality.planes, quality.ssim_mode)
+            p["has_q"] = True
+        if want_c and p["j1"] > p["j0"]:
+            m = p["j1"] - p["j0"]
+            if host:
+                h, w = dist.shape[1], dist.shape[2]
+                batch = DeviceFrames(dd.ptr + (1 + p["first"]) * fb, m, h, w, frame_stride=fb * p["step"], owner=dd)
+                prev0 = DeviceFrames(dd.ptr + (1 + p["prev_slot"]) * fb, 1, h, w, owner=dd)
+            else:
+                # every frame_interval-th frame, zero-copy: the batch is a strided view of the resident clip
+                s0 = int(idx[1 + p["j0"]])
+                batch = DeviceFrames(dist.ptr + s0 * dist.frame_stride, m, dist.h, dist.w,
+                                     frame_stride=dist.frame_stride * complexity.interval, row_stride=dist.row_stride,
+                                     owner=dist, channels=dist.channels)
+                prev0 = dist.frame(int(idx[p["j0"]]))
+            eng.complexity_submit(batch, prev0, complexity.mask, params)
+            p["has_c"] = True
+
+    sse, ssim = [], []
+
+    def collect(p, eng):
+        if p["has_q"]:
+            res = eng.quality_wait()
+            sse.append(res["sse"])
+            ssim.append(res["ssim"])
+        if p["has_c"]:
+            rec = eng.complexity_wait()
+        if staged:
+            free_slots.append(p["slot"])  # every copy out of the slot has completed
+        if p["has_q"] and on_quality is not None:
+            on_quality(p["q0"], sse[-1], ssim[-1])
+        if p["has_c"]:
+            for kind in KINDS:
+                if complexity.mask & MASK[kind]:
+                    series[kind].extend(tails.scalars(kind, rec, complexity.motion_mode))
+            if complexity.mask & N.M_TEMPORAL_DCT:
+                t = tails.scalars("temporal", rec)
+                # the reference's first pair only primes prev_gray_frame (:533-537)
+                series["temporal"].extend(t[1:] if p["j0"] == 0 else t)
+
+    pending = []
+    try:
+        nxt = plan(0)
+        start_fill(nxt)
+        for k in range(len(chunks)):
+            p, eng = nxt, lanes[k % len(lanes)]
+            if len(pending) == len(lanes):
+                collect(*pending.pop(0))
+            if k + 1 < len(chunks):  # the copiers work on chunk k + 1 while chunk k is enqueued and runs
+                nxt = plan(k + 1)
+                start_fill(nxt)
+            submit(p, eng)
+            pending.append((p, eng))
+        while pending:
+            collect(*pending.pop(0))
+    except BaseException:
+        _abandon(lanes)
+        raise
+    q = (np.concatenate(sse), np.concatenate(ssim)) if want_q else None
+    return q, series
+
+
+def _abandon(lanes):
+    """After a failure inside a pass (the reference's convention: log, re-raise, nothing left running,
+    video_processing.py:295-297): wait out whatever the lanes still have pending, so that nothing reads the ring, the
+    lane buffers or the caller's frames any more when the error surfaces, and the engines stay usable."""
+    for eng in lanes:
+        for pend, wait in (("_pending_q", eng.quality_wait), ("_pending_c", eng.complexity_wait)):
+            try:
+                if getattr(eng, pend, None):
+                    wait()
+            except Exception:
+                setattr(eng, pend, None)
+        try:
+            eng.sync()
+        except Exception:
+            pass
+
+
+def _device_of(frames):
+    """the device a resident clip lives on (None = the default engine's)"""
+    if not isinstance(frames, DeviceFrames):
+        return None
+    own = getattr(frames, "_owner", None)
+    while isinstance(own, DeviceFrames):
+        own = getattr(own, "_owner", None)
+    if hasattr(own, "engine"):            # a DeviceBuffer knows its engine
+        return own.engine.device
+    return getattr(getattr(own, "device", None), "index", None)  # a torch tensor its device index

@@ -16,7 +16,8 @@ import re
 import numpy as np
 
 from . import _native as N
-from .complexity_metrics import _open_frames, get_engine, get_engine_pair
+from . import stream
+from .complexity_metrics import _open_frames
 from .engine import DeviceFrames, bgr_planes, gray_planes, yuv420p_planes
 
 LAYOUTS = {
@@ -25,78 +26,116 @@ LAYOUTS = {
     "gray": (gray_planes, "y"),       # [N,H,W]
     "yuv420p": (yuv420p_planes, "yuv"),  # [N, H*W*3/2] planar
 }
+_SSIM_MODES = {"gauss": N.SSIM_GAUSS, "ffmpeg": N.SSIM_FFMPEG}
+
+
+def _geometry(reference, layout, height, width):
+    if isinstance(reference, DeviceFrames):
+        return reference.h, reference.w
+    if layout == "yuv420p":
+        return height, width
+    return reference.shape[1], reference.shape[2]
+
+
+def _host_stream(a):
+    if isinstance(a, DeviceFrames):
+        return a
+    a = np.asarray(a)
+    if a.dtype != np.uint8:  # a silent cast would turn float frames in 0..1 into all-zero planes
+        raise ValueError("frames must be uint8 (got %s)" % a.dtype)
+    return a
 
 
 def frame_quality(reference, distorted, layout="bgr24", ssim_mode="gauss", height=None, width=None, engine=None,
-                  batch_size=64):
-    """Per-frame SSE and SSIM per plane.  Returns (sse [n,p] uint64, ssim [n,p] float64, plane sizes)."""
-    mode = {"gauss": N.SSIM_GAUSS, "ffmpeg": N.SSIM_FFMPEG}[ssim_mode]
-    build, _ = LAYOUTS[layout]
-    on_device = isinstance(reference, DeviceFrames)
-    if on_device:
-        h, w, n = reference.h, reference.w, reference.n
-    else:
-        reference = np.asarray(reference)
-        distorted = np.asarray(distorted)
-        n = reference.shape[0]
-        if layout == "yuv420p":
-            h, w = height, width
-        else:
-            h, w = reference.shape[1], reference.shape[2]
-    planes = build(h, w)
-    # host streams longer than one batch: two engines ping-pong so batch k+1's copy overlaps batch k's kernels
-    engs = [engine or get_engine()] if (engine is not None or on_device or n <= batch_size) else list(get_engine_pair())
-    sse, ssim, pending = [], [], []
+                  batch_size=64, on_chunk=None):
+    """Per-frame SSE and SSIM per plane.  Returns (sse [n,p] uint64, ssim [n,p] float64, plane sizes).
+    One pass (stream.run): chunks of up to batch_size frame pairs alternate between two engines; host streams travel
+    from the caller's pinned memory or through the pinned ring.  on_chunk(first_frame, sse, ssim) sees every finished
+    chunk in frame order while the next one is on the GPU."""
+    reference, distorted = _host_stream(reference), _host_stream(distorted)
+    if not isinstance(reference, DeviceFrames) and reference.shape != distorted.shape:
+        raise ValueError("ref and dist must have the same shape")
+    h, w = _geometry(reference, layout, height, width)
+    planes = LAYOUTS[layout][0](h, w)
+    q, _ = stream.run(distorted, reference, quality=stream.Quality(planes, _SSIM_MODES[ssim_mode]),
+                      batch_size=batch_size, engine=engine, on_quality=on_chunk)
+    return q[0], q[1], [(p[0], p[1]) for p in planes]
 
-    def collect(eng):
-        res = eng.quality_wait()
-        sse.append(res["sse"])
-        ssim.append(res["ssim"])
 
-    for k, a in enumerate(range(0, n, batch_size)):
-        b = min(a + batch_size, n)
-        eng = engs[k % len(engs)]
-        if len(pending) == len(engs):
-            collect(pending.pop(0))
-        if on_device:
-            eng.quality_submit(reference.slice(a, b), distorted.slice(a, b), planes, mode)
-        else:
-            eng.quality_submit(reference[a:b], distorted[a:b], planes, mode)
-        pending.append(eng)
-    while pending:
-        collect(pending.pop(0))
-    sizes = [(p[0], p[1]) for p in planes]
-    return np.concatenate(sse), np.concatenate(ssim), sizes
+# ---------------------------------------------------------------------------
+# FFmpeg-format stats lines, a chunk of frames at a time
+# ---------------------------------------------------------------------------
+def _db(x):
+    """10 log10(x) with inf for x = inf (FFmpeg prints "inf")"""
+    with np.errstate(divide="ignore"):
+        return 10.0 * np.log10(x)
 
 
 def _psnr(mse, peak=255.0):
-    # FFmpeg vf_psnr.c get_psnr(): 10*log10(max^2 / mse); mse == 0 -> inf
-    return 10.0 * math.log10(peak * peak / mse) if mse > 0 else float("inf")
+    """FFmpeg vf_psnr.c get_psnr(): 10*log10(max^2 / mse); mse == 0 -> inf (the expression the stats lines use)"""
+    with np.errstate(divide="ignore"):
+        return float(_db(np.float64(peak * peak) / np.float64(mse)))
+
+
+def psnr_stats_lines(n0, sse, sizes, comps):
+    """Lines n0.. of FFmpeg's psnr stats_file (vf_psnr.c) for sse [m,p]: per-component mse = sse/(w*h); mse_avg
+    weights components by plane area; psnr = 10 log10(255^2 / mse) (get_psnr(); mse 0 -> inf); 2-decimal text."""
+    sse = np.asarray(sse, np.float64).reshape(-1, len(sizes))
+    areas = [w * h for w, h in sizes]
+    total = float(sum(areas))
+    mse = sse / np.asarray(areas, np.float64)
+    mse_avg = np.zeros(len(sse))
+    for j, a in enumerate(areas):
+        mse_avg = mse_avg + mse[:, j] * (a / total)
+    with np.errstate(divide="ignore"):
+        cols = [np.arange(n0, n0 + len(sse), dtype=np.float64), mse_avg] + [mse[:, j] for j in range(len(areas))]
+        cols += [_db(255.0 * 255.0 / mse_avg)] + [_db(255.0 * 255.0 / mse[:, j]) for j in range(len(areas))]
+    fmt = ("n:%d mse_avg:%0.2f " + "".join("mse_%c:%%0.2f " % c for c in comps) + "psnr_avg:%0.2f "
+           + "".join("psnr_%c:%%0.2f " % c for c in comps) + "\n")
+    return (fmt * len(sse)) % tuple(np.column_stack(cols).ravel().tolist())
+
+
+def ssim_stats_lines(n0, ssim, sizes, comps):
+    """Lines n0.. of FFmpeg's ssim stats_file (vf_ssim.c): 'n:1 Y:0.99 U:.. V:.. All:0.99 (20.0)'."""
+    ssim = np.asarray(ssim, np.float64).reshape(-1, len(sizes))
+    areas = [w * h for w, h in sizes]
+    total = float(sum(areas))
+    allv = np.zeros(len(ssim))
+    for j, a in enumerate(areas):
+        allv = allv + ssim[:, j] * (a / total)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        db = np.where(allv < 1.0, _db(1.0 / (1.0 - allv)), np.inf)
+    cols = [np.arange(n0, n0 + len(ssim), dtype=np.float64)] + [ssim[:, j] for j in range(len(areas))] + [allv, db]
+    fmt = "n:%d " + "".join("%c:%%f " % c.upper() for c in comps) + "All:%f (%f)\n"
+    return (fmt * len(ssim)) % tuple(np.column_stack(cols).ravel().tolist())
 
 
 def psnr_stats_line(n, sse_row, sizes, comps):
-    """One line of FFmpeg's psnr stats_file (vf_psnr.c): per-component mse = sse/(w*h);
-    mse_avg weights components by plane area; 2-decimal text."""
-    areas = [w * h for w, h in sizes]
-    comp_mse = [float(s) / a for s, a in zip(sse_row, areas)]
-    total = float(sum(areas))
-    mse_avg = sum(m * (a / total) for m, a in zip(comp_mse, areas))
-    parts = ["n:%d mse_avg:%0.2f " % (n, mse_avg)]
-    parts += ["mse_%c:%0.2f " % (c, m) for c, m in zip(comps, comp_mse)]
-    parts.append("psnr_avg:%0.2f " % _psnr(mse_avg))
-    parts += ["psnr_%c:%0.2f " % (c, _psnr(m)) for c, m in zip(comps, comp_mse)]
-    return "".join(parts) + "\n"
+    return psnr_stats_lines(n, [list(sse_row)], sizes, comps)
 
 
 def ssim_stats_line(n, ssim_row, sizes, comps):
-    """One line of FFmpeg's ssim stats_file (vf_ssim.c): 'n:1 Y:0.99 U:.. V:.. All:0.99 (20.0)'."""
-    areas = [w * h for w, h in sizes]
-    total = float(sum(areas))
-    allv = sum(float(s) * (a / total) for s, a in zip(ssim_row, areas))
-    db = 10.0 * math.log10(1.0 / (1.0 - allv)) if allv < 1.0 else float("inf")
-    parts = ["n:%d " % n] + ["%c:%f " % (c.upper(), float(s)) for c, s in zip(comps, ssim_row)]
-    parts.append("All:%f (%f)\n" % (allv, db))
-    return "".join(parts)
+    return ssim_stats_lines(n, [list(ssim_row)], sizes, comps)
+
+
+class _StatsWriter:
+    """Writes the two stats files chunk by chunk (stream.run's on_quality), in FFmpeg's component order."""
+
+    def __init__(self, psnr_log, ssim_log, layout, sizes):
+        comps = LAYOUTS[layout][1]
+        # FFmpeg lists rgb components in r,g,b order whatever the packing
+        self.order = [2, 1, 0] if layout == "bgr24" else list(range(len(comps)))
+        self.names = "rgb" if layout == "bgr24" else comps
+        self.sizes = [sizes[j] for j in self.order]
+        self.fp, self.fs = open(psnr_log, "w"), open(ssim_log, "w")
+
+    def __call__(self, first_frame, sse, ssim):
+        self.fp.write(psnr_stats_lines(first_frame + 1, sse[:, self.order], self.sizes, self.names))
+        self.fs.write(ssim_stats_lines(first_frame + 1, ssim[:, self.order], self.sizes, self.names))
+
+    def close(self):
+        self.fp.close()
+        self.fs.close()
 
 
 def _open_quality_stream(src, layout, height, width):
@@ -111,7 +150,7 @@ def _open_quality_stream(src, layout, height, width):
 
 
 def run_ffmpeg_metrics(reference_video, distorted_video, psnr_log, ssim_log, vmaf_log, vmaf_model_path=None,
-                       layout="bgr24", ssim_mode="gauss", height=None, width=None):
+                       layout="bgr24", ssim_mode="gauss", height=None, width=None, batch_size=64):
     """video_processing.py:270-297 — PSNR and SSIM between two streams, one stats line per frame.
     Streams: [N,H,W,3] BGR arrays / .npy (components r,g,b as FFmpeg labels RGB input), planar yuv420p
     arrays with height/width, or .y4m files (components y,u,v — what FFmpeg sees for an H.264 clip)."""
@@ -119,17 +158,12 @@ def run_ffmpeg_metrics(reference_video, distorted_video, psnr_log, ssim_log, vma
     dist, layout_d, _, _ = _open_quality_stream(distorted_video, layout, height, width)
     if layout_d != layout:
         raise ValueError("reference and distorted streams must share a pixel layout")
-    sse, ssim, sizes = frame_quality(ref, dist, layout, ssim_mode, height, width)
-    comps = LAYOUTS[layout][1]
-    # FFmpeg lists rgb components in r,g,b order whatever the packing
-    order = [2, 1, 0] if layout == "bgr24" else list(range(len(comps)))
-    names = "rgb" if layout == "bgr24" else comps
-    with open(psnr_log, "w") as f:
-        for i in range(sse.shape[0]):
-            f.write(psnr_stats_line(i + 1, [sse[i][j] for j in order], [sizes[j] for j in order], names))
-    with open(ssim_log, "w") as f:
-        for i in range(ssim.shape[0]):
-            f.write(ssim_stats_line(i + 1, [ssim[i][j] for j in order], [sizes[j] for j in order], names))
+    h, w = _geometry(ref, layout, height, width)
+    wr = _StatsWriter(psnr_log, ssim_log, layout, [(p[0], p[1]) for p in LAYOUTS[layout][0](h, w)])
+    try:
+        frame_quality(ref, dist, layout, ssim_mode, height, width, batch_size=batch_size, on_chunk=wr)
+    finally:
+        wr.close()
     return None
 
 
@@ -166,12 +200,30 @@ def process_video_and_extract_metrics(input_video, encoded_video, config, csv_fi
     uid = uuid.uuid4().hex
     tmp = tempfile.gettempdir()
     psnr_log, ssim_log, vmaf_log = (os.path.join(tmp, "%s_%s.log" % (k, uid)) for k in ("psnr", "ssim", "vmaf"))
+    batch_size = config.get("batch_size", 100)
     try:
-        run_ffmpeg_metrics(input_video, encoded_video, psnr_log, ssim_log, vmaf_log, config.get("vmaf_model_path"))
-        enc = _open_frames(encoded_video)
+        y4m = any(isinstance(v, str) and v.endswith(".y4m") for v in (input_video, encoded_video))
+        if y4m:
+            # planar quality inputs and a BGR complexity input are different bytes: two passes
+            run_ffmpeg_metrics(input_video, encoded_video, psnr_log, ssim_log, vmaf_log, config.get("vmaf_model_path"))
+            enc = _open_frames(encoded_video)
+            series = cm.complexity_series(enc, rw, rh, interval, batch_size)
+        else:
+            # ONE pass (:216 and :242 read the same encoded stream): every chunk is uploaded once, the quality kernels
+            # read all of its frames and the complexity kernels every interval-th of them
+            ref, enc = _open_frames(input_video), _open_frames(encoded_video)
+            h, w = _geometry(enc, "bgr24", None, None)
+            planes = bgr_planes(h, w)
+            wr = _StatsWriter(psnr_log, ssim_log, "bgr24", [(p[0], p[1]) for p in planes])
+            try:
+                _q, series = stream.run(enc, ref, quality=stream.Quality(planes, N.SSIM_GAUSS),
+                                        complexity=stream.Complexity((rw, rh), interval, motion_mode=cm._motion_mode),
+                                        batch_size=batch_size, on_quality=wr)
+            finally:
+                wr.close()
         resolution = "%dx%d" % (enc.shape[2], enc.shape[1]) if hasattr(enc, "shape") else "%dx%d" % (enc.w, enc.h)
         metrics = extract_metrics_from_logs(psnr_log, ssim_log, vmaf_log, input_video, crf, bitrate, resolution, frame_rate)
-        t = cm.calculate_average_scene_complexity(encoded_video, rw, rh, frame_interval=interval, fps=frame_rate)
+        t = cm.pool_series(series, enc, interval, batch_size=batch_size, fps=frame_rate)
         if column_order == "reference":   # (:235-242) motion, dct, temporal, hist, edge, orb, colour, fps
             names = ("Advanced Motion Complexity", "DCT Complexity", "Temporal DCT Complexity", "Histogram Complexity",
                      "Edge Detection Complexity", "ORB Feature Complexity", "Color Histogram Complexity",

@@ -1,0 +1,177 @@
+"""stream.run - the one-pass host side of the reference's entry points - on the GPU: wherever the frames live
+(pageable NumPy, np.load(mmap_mode="r"), pinned, device) and however the clip is chunked, the series and the
+quality numbers are the same bits; the fused pass (process_video_and_extract_metrics: one upload for both halves)
+equals the two separate passes; vqa_trim gives the memory back and changes no result; the table caches stay bounded."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import pipeline as pl
+
+pytestmark = pytest.mark.gpu
+
+
+def _clip(n, h, w, seed=0):
+    from rtvqa_amd import synth
+    return synth.s_natural(n, h, w, seed=seed)
+
+
+def _same_series(a, b):
+    for k in ("motion", "dct", "hist", "edge", "orb", "color", "temporal"):
+        assert len(a[k]) == len(b[k]), k
+        assert all((x == y) or (x != x and y != y) for x, y in zip(a[k], b[k])), k
+    assert a["range"] == b["range"]
+
+
+@pytest.mark.parametrize("interval,batch", [(1, 7), (3, 4), (10, 100)])
+def test_every_residence_gives_the_same_bits(tmp_path, interval, batch):
+    from rtvqa_amd import complexity_metrics as cm
+    from rtvqa_amd import stream
+    from rtvqa_amd import video_processing as vp
+    from rtvqa_amd import synth
+    n, h, w = 43, 120, 168
+    ref = _clip(n, h, w, seed=50 + interval)
+    dist = synth.distort(ref)
+    eng = cm.get_engine()
+    assert not eng.is_pinned(dist)
+    pin_r, pin_d = eng.alloc_pinned(ref.shape), eng.alloc_pinned(dist.shape)
+    pin_r[...] = ref
+    pin_d[...] = dist
+    assert eng.is_pinned(pin_d) and eng.is_pinned(pin_d[5:])
+    np.save(str(tmp_path / "d.npy"), dist)
+    np.save(str(tmp_path / "r.npy"), ref)
+    dev_r, dev_d = eng.upload(ref), eng.upload(dist)
+    assert not eng.is_pinned(np.zeros(4, np.uint8))
+    want = cm.complexity_series(dist, 64, 48, interval, batch_size=1000, engine=eng)   # one chunk, one engine
+    for src in (dist, pin_d, str(tmp_path / "d.npy"), dev_d, dist[:, :, :, :]):
+        _same_series(cm.complexity_series(src, 64, 48, interval, batch_size=batch), want)
+    # the reference-shaped oracle pipeline on the same clip (counts exact, floats 1e-4)
+    t = cm.calculate_average_scene_complexity(pin_d, 64, 48, frame_interval=interval, batch_size=batch)
+    o = pl.calculate_average_scene_complexity(list(dist), 64, 48, frame_interval=interval, dct_mode="full")
+    for k in (2, 3, 4, 5):
+        assert (np.isnan(t[k]) and np.isnan(o[k])) or float(t[k]) == pytest.approx(float(o[k]), rel=1e-12), k
+    for k in (0, 1, 6):
+        assert (np.isnan(t[k]) and np.isnan(o[k])) or float(t[k]) == pytest.approx(float(o[k]), rel=1e-4), k
+    q_want = vp.frame_quality(ref, dist, batch_size=1000, engine=eng)
+    for r, d in ((ref, dist), (pin_r, pin_d), (dev_r, dev_d), (pin_r, dist),
+                 (np.load(str(tmp_path / "r.npy"), mmap_mode="r"), np.load(str(tmp_path / "d.npy"), mmap_mode="r"))):
+        q = vp.frame_quality(r, d, batch_size=batch)
+        assert np.array_equal(q[0], q_want[0]) and np.array_equal(q[1], q_want[1])
+    # the fused pass: both halves from one upload
+    for r, d in ((ref, dist), (pin_r, pin_d), (dev_r, dev_d)):
+        got_q, got_s = stream.run(d, r, quality=stream.Quality(vp.bgr_planes(h, w)),
+                                  complexity=stream.Complexity((64, 48), interval), batch_size=batch)
+        assert np.array_equal(got_q[0], q_want[0]) and np.array_equal(got_q[1], q_want[1])
+        _same_series(got_s, want)
+    eng.free_pinned(pin_r)
+    eng.free_pinned(pin_d)
+
+
+def test_region_of_interest_and_short_clips_through_the_ring():
+    from rtvqa_amd import complexity_metrics as cm
+    big = _clip(9, 100, 140, seed=77)
+    roi = big[:, 3:83, 5:133]                       # padded rows: the ring compacts them
+    want = cm.complexity_series(np.ascontiguousarray(roi), 64, 64, 2, batch_size=100)
+    _same_series(cm.complexity_series(roi, 64, 64, 2, batch_size=2), want)
+    assert cm.complexity_series(big[:1], 64, 64, 1)["dct"] == []          # nothing to measure: no engine work
+    one = cm.complexity_series(big[:2], 64, 64, 1)
+    assert len(one["dct"]) == 1 and one["temporal"] == []
+
+
+def test_pipeline_row_is_one_pass_and_matches_the_two_calls(tmp_path):
+    """process_video_and_extract_metrics (video_processing.py:216 + :242 on the same encoded stream) = the numbers of
+    run_ffmpeg_metrics + calculate_average_scene_complexity called one after the other."""
+    from rtvqa_amd import complexity_metrics as cm
+    from rtvqa_amd import synth
+    from rtvqa_amd import video_processing as vp
+    ref = _clip(33, 96, 128, seed=5)
+    enc = synth.distort(ref)
+    cfg = {"crf": 23, "resize_width": 64, "resize_height": 64, "frame_interval": 4, "batch_size": 5}
+    m = vp.process_video_and_extract_metrics(ref, enc, cfg, csv_file=str(tmp_path / "a.csv"), column_order="fixed")
+    pl_, sl_ = str(tmp_path / "p.log"), str(tmp_path / "s.log")
+    vp.run_ffmpeg_metrics(ref, enc, pl_, sl_, str(tmp_path / "v.json"))
+    m2 = vp.extract_metrics_from_logs(pl_, sl_, str(tmp_path / "v.json"), "x", 23, 0, "128x96", 30.0)
+    assert m["PSNR"] == m2["PSNR"] and m["SSIM"] == m2["SSIM"]
+    assert len(open(pl_).read().splitlines()) == 33
+    t = cm.calculate_average_scene_complexity(enc, 64, 64, frame_interval=4)
+    names = ("Advanced Motion Complexity", "DCT Complexity", "Histogram Complexity", "Edge Detection Complexity",
+             "ORB Feature Complexity", "Color Histogram Complexity", "Temporal DCT Complexity", "Framerate Variation")
+    for name, v in zip(names, t):
+        assert m[name] == v, name
+
+
+def _free_bytes():
+    import torch
+    return torch.cuda.mem_get_info(0)[0]
+
+
+def test_trim_gives_the_memory_back_and_changes_nothing():
+    """vqa_trim after a 2160p Farneback submit: the device's free memory returns to within 64 MiB of what it was
+    before the submit, a pending batch refuses the trim, and the same ctx then returns oracle-exact records."""
+    import rtvqa_amd
+    from rtvqa_amd import _native as N
+    with rtvqa_amd.Engine(0) as eng:
+        small = _clip(3, 144, 256, seed=9)
+        first = eng.complexity(small[1:], prev0=small[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        eng.trim()
+        base = _free_bytes()
+        big = eng.upload(_clip(3, 2160, 3840, seed=10))
+        held = _free_bytes()
+        eng.complexity_submit(big.slice(1, 3), big.frame(0), N.M_ALL, eng.make_params(motion_mode=N.MOTION_FARNEBACK, dct_mode=N.DCT_FULL))
+        assert eng.lib.vqa_trim(eng.ctx) == N.VQA_ERR_STATE          # a batch is pending
+        rec = eng.complexity_wait()
+        assert rec[0]["flow_mag_mean"] > 0
+        grown = _free_bytes()
+        assert held - grown > (1 << 30)                                # GiB-sized scratch is what trim is for
+        eng.trim()
+        big._owner.free()
+        after = _free_bytes()
+        assert abs(after - base) <= (64 << 20), (base, held, grown, after)
+        again = eng.complexity(small[1:], prev0=small[0], mask=N.M_ALL, dct_mode=N.DCT_BLOCK8)
+        for f in first.dtype.names:
+            if f != "hyst_steps":
+                assert first[f].tobytes() == again[f].tobytes(), f
+        g, gp = co.bgr2gray(small[1]), co.bgr2gray(small[0])
+        assert int(again[0]["edge_count"]) == co.canny(g, 100, 200)[0]
+        assert (again[0]["hist_gray"] == co.hist_u8(g)).all()
+        assert int(again[0]["sad_sum"]) == co.block_sad(gp, g, 7)[1]
+
+
+def test_table_caches_stay_bounded_over_200_geometries():
+    """Every distinct (frame size, resize) pair adds device tables; beyond VQA_TABLE_CACHE_GEOMETRIES the least recently
+    used set goes.  200 geometries on one ctx: the device's free memory stays where it was after the first 20, and an
+    evicted geometry still gives oracle-exact bins when it comes back."""
+    import rtvqa_amd
+    from rtvqa_amd import _native as N
+    rng = np.random.default_rng(0)
+    with rtvqa_amd.Engine(0) as eng:
+        fr = rng.integers(0, 256, (2, 96, 160, 3), dtype=np.uint8)
+        dev = eng.upload(fr)
+        first = None
+        mark = None
+        for i in range(200):
+            rw, rh = 130 + 2 * (i % 100), 128 + 2 * (i // 100)      # even, 2-3-5-smooth or not: FFT plans and dense matrices
+            rec = eng.complexity(dev.slice(1, 2), prev0=dev.frame(0), mask=N.M_GRAY_HIST | N.M_DCT | N.M_TEMPORAL_DCT,
+                                 resize=(rw, rh), dct_mode=N.DCT_FULL)
+            if i == 0:
+                first = rec.copy()
+            if i == 20:
+                mark = _free_bytes()
+        assert mark - _free_bytes() <= (32 << 20)
+        rec = eng.complexity(dev.slice(1, 2), prev0=dev.frame(0), mask=N.M_GRAY_HIST | N.M_DCT | N.M_TEMPORAL_DCT,
+                             resize=(130, 128), dct_mode=N.DCT_FULL)
+        assert rec["hist_gray"].tobytes() == first["hist_gray"].tobytes()
+        assert rec["dct_energy"].tobytes() == first["dct_energy"].tobytes()
+        g = co.bgr2gray(co.resize_linear(fr[1], 130, 128))
+        assert (rec[0]["hist_gray"] == co.hist_u8(g)).all()
+
+
+def test_release_buffers_then_the_api_still_works():
+    from rtvqa_amd import complexity_metrics as cm
+    clip = _clip(12, 90, 120, seed=3)
+    a = cm.complexity_series(clip, 64, 64, 1, batch_size=4)
+    cm.release_buffers()
+    _same_series(cm.complexity_series(clip, 64, 64, 1, batch_size=4), a)
