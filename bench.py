@@ -25,12 +25,21 @@ process pool that reproduces the reference's process_in_batches, timed on this
 box's host cores) and "verified": the result records of the LAST TIMED step at a
 few batch positions are compared with what the oracle expects for those frames
 (expectations computed before the process touches the GPU); a mismatch is fatal
-on every rank (exit code 4) and no line is printed.
+on every rank (exit code 4) and no line is printed.  With the default modes of a
+full-suite workload the line also carries "api_end_to_end": the SAME clip through
+the reference-shaped Python entry point process_video_and_extract_metrics
+(video_processing.py:216 + :242: run_ffmpeg_metrics + calculate_average_scene_complexity,
+one pass) from HBM, from pinned host memory and from pageable host memory - the
+drop-in surface on the measured path, stats files and CSV row included; never `value`.
 
 Workloads (BASELINE.json configs):
   c3  1920x1080 full complexity suite + PSNR/SSIM          [default: the config BASELINE.json's metric is quoted on]
   c2  1920x1080, frame_interval=1, PSNR + SSIM (Gaussian) + 8x8 DCT (energy + temporal)
   c4  3840x2160 full suite
+  c1  BASELINE configs[0], the reference's own config.json: 64x64 resize, frame_interval=10 on a 300-frame 1080p
+      clip, through process_video_and_extract_metrics (PSNR/SSIM of all 300 frame pairs at 1080p + the complexity
+      suite of every 10th frame at 64x64, full-frame DCT as the reference computes it at that size).  A step = one
+      call on the clip; `value` = source frames/s with the clip resident in HBM, api_end_to_end = from host memory
   c3ref  1920x1080, the REFERENCE's own definitions in one line: Farneback motion (complexity_metrics.py:340),
       full-frame DCT energy + temporal L1 (:363, :574-579), FFmpeg vf_ssim + psnr on yuv420p planes
       (video_processing.py:275-276), gray + colour histograms, Canny, ORB count; 64 frames per step
@@ -59,6 +68,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s s
 CSRC = os.path.join(REPO, "real-time-video-quality-analysis_amd", "csrc")
 
 WORKLOADS = {
+    "c1": dict(h=1080, w=1920, batch=300, full=True, api=True,
+               name="config.json defaults: 300 x 1920x1080 clip, resize 64x64, frame_interval=10, "
+                    "process_video_and_extract_metrics = PSNR/SSIM(gauss) of every frame pair + complexity suite of every 10th frame"),
     "c2": dict(h=1080, w=1920, batch=256, full=False,
                name="1920x1080 frame_interval=1 PSNR+SSIM(gauss 11x11)+8x8 DCT(energy+temporal), BGR24 pairs"),
     "c3": dict(h=1080, w=1920, batch=256, full=True,
@@ -343,6 +355,358 @@ def end_to_end(rtvqa_amd, N, device, eng, ref_pin, dist_pin, h, w, full, mask, p
 
 
 # ---------------------------------------------------------------------------
+def reduce_over_ranks(td, dt, pooled_vals, device, world, rehearsal, stub, red_dev):
+    """max of the timed region over ranks, the path's ONE data collective (a SUM all-reduce of a few pooled float64
+    scalars: RCCL over xGMI, latency-bound) and the device census.  td None = no process group.  -> (dt, devices)"""
+    if td is None:
+        return dt, [device]
+    import torch
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    td.all_reduce(tmax, op=td.ReduceOp.MAX)
+    dt = float(tmax.item())
+    pooled = torch.tensor(pooled_vals, dtype=torch.float64, device=red_dev)
+    td.all_reduce(pooled, op=td.ReduceOp.SUM)
+    seen = [None] * world
+    td.all_gather_object(seen, device)
+    devices = sorted(set(int(x) for x in seen))
+    if not rehearsal and not stub and len(devices) != world:
+        sys.stderr.write("[bench] FATAL: %d ranks share %d devices %s\n" % (world, len(devices), devices))
+        os._exit(3)
+    return dt, devices
+
+
+# ---------------------------------------------------------------------------
+def kernel_report(prof, alg_bytes, valu_fma, mfma_flops, workload, frames_per_launch, default_mode):
+    """prof: {kernel: (total ms, launches)} of a serial pass -> (per-kernel table, roofline of the dominant kernel).
+    alg_bytes / valu_fma / mfma_flops: algorithmic bytes / counted fp32 FMAs / dense flops PER LAUNCH of the kernels that have such a
+    figure (SURVEY.md 8d x the frames one launch covers)."""
+    kernels = {}
+    for name, (ms, cnt) in prof.items():
+        per = ms / cnt
+        ent = {"ms_per_launch": round(per, 4), "launches": cnt, "share_of_kernel_time": 0.0}
+        if name in alg_bytes:
+            gbs = alg_bytes[name] / (per * 1e-3) / 1e9
+            ent.update({"alg_bytes": alg_bytes[name], "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
+        kernels[name] = ent
+    tot = sum(ms for ms, _ in prof.values()) or 1.0
+    for name, (ms, _) in prof.items():
+        kernels[name]["share_of_kernel_time"] = round(ms / tot, 4)
+    for name, fma in valu_fma.items():
+        if name in kernels:
+            tf = 2.0 * fma / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
+            kernels[name].update({"fma": fma, "TFLOPps": round(tf, 1), "frac_fp32": round(tf / 157.3, 4)})
+    for name, fl in mfma_flops.items():
+        if name in kernels:
+            tf = fl / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
+            kernels[name].update({"flops": fl, "TFLOPps": round(tf, 1), "frac_mfma_f32": round(tf / 157.3, 4)})
+    cands = [k for k in prof if k in alg_bytes or k in mfma_flops]
+    dom = max(cands, key=lambda k: prof[k][0]) if cands else None
+    if dom is None:
+        return kernels, None
+    if dom in mfma_flops:
+        return kernels, {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": kernels[dom]["frac_mfma_f32"], "traffic": None, "traffic_source": "none",
+                         "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = flops per launch / mean HIP-event duration"}
+    traffic, tsrc = pmc_traffic(workload, dom, frames_per_launch, default_mode)
+    if kernels[dom]["frac_hbm"] < 0.2 and "frac_fp32" in kernels[dom]:
+        # a kernel this far below the HBM roof that does counted fp32 work is reported against the roof it
+        # really has: the vector ALUs (VERDICT round 2 #5); the HBM figures stay beside it
+        roof = {"bound": "valu_fp32", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": 157.3,
+                "unit": "TFLOP/s", "frac": kernels[dom]["frac_fp32"], "fma": kernels[dom]["fma"],
+                "frac_hbm": kernels[dom]["frac_hbm"], "achieved_hbm_GBps": kernels[dom]["GBps"],
+                "peak_hbm_GBps": HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                "alg_bytes": alg_bytes[dom],
+                "note": "achieved = 2 x 88 FMA per pixel and plane / mean HIP-event duration; fp32 vector peak "
+                        "157.3 TFLOP/s at 2.4 GHz; the kernel issues packed FMAs at the calibrated rate "
+                        "(DESIGN.md 4b/5) and the chip holds ~1.9-2.05 GHz under it (profiles/round*_clock.json); "
+                        "frac_hbm = algorithmic bytes / time / 8 TB/s is kept for the HBM view"}
+    else:
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "traffic_source": tsrc,
+                "alg_bytes": alg_bytes[dom],
+                "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"}
+    return kernels, roof
+
+
+# ---------------------------------------------------------------------------
+def api_rates(vp, cm, clips, config, steps, frames):
+    """process_video_and_extract_metrics (the reference's caller of run_ffmpeg_metrics + calculate_average_scene_complexity,
+    video_processing.py:216, :242) on the same clip held three ways; one warm call (allocations, the pinned ring), then
+    `steps` timed calls each.  -> {name_fps: ...}, last metrics dict"""
+    import tempfile
+    out, metrics = {}, None
+    with tempfile.TemporaryDirectory() as tmp:
+        csv = os.path.join(tmp, "bench_api.csv")
+        for name, (r, d) in clips.items():
+            metrics = vp.process_video_and_extract_metrics(r, d, config, csv_file=csv)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                metrics = vp.process_video_and_extract_metrics(r, d, config, csv_file=csv)
+            out[name + "_fps"] = round(frames * steps / (time.perf_counter() - t0), 1)
+    return out, metrics
+
+
+def api_end_to_end(rtvqa_amd, eng, ref_dev, dist_dev, ref_pin, dist_pin, h, w, steps, value, e2e_fps, config=None):
+    """The drop-in Python surface on the measured path: resident / pinned host / pageable host clip of the workload's
+    geometry through process_video_and_extract_metrics.  Measured after the timed region; never `value`."""
+    from rtvqa_amd import complexity_metrics as cm
+    from rtvqa_amd import video_processing as vp
+    n = dist_pin.shape[0]
+    config = config or {"crf": 23, "resize_width": w, "resize_height": h, "frame_interval": 1, "batch_size": 100}
+    ref_pg, dist_pg = np.array(ref_pin), np.array(dist_pin)  # ordinary (pageable) copies, as a caller that decoded a file holds them
+    rates, m = api_rates(vp, cm, {"resident": (ref_dev, dist_dev), "host_pinned": (ref_pin, dist_pin),
+                                  "host_pageable": (ref_pg, dist_pg)}, config, steps, n)
+    cm.release_buffers()  # the pinned ring and lane buffers of the passes: given back (stream.release_buffers)
+    out = dict(rates, frames_per_call=n, calls=steps, config=config,
+               entry_point="rtvqa_amd.video_processing.process_video_and_extract_metrics (= run_ffmpeg_metrics + "
+                           "calculate_average_scene_complexity in ONE pass; stats files, regex parse and CSV row included)",
+               PSNR=m.get("PSNR"), SSIM=m.get("SSIM"))
+    if value:
+        out["resident_vs_value"] = round(rates["resident_fps"] / value, 3)
+    if e2e_fps:
+        out["host_pinned_vs_end_to_end"] = round(rates["host_pinned_fps"] / e2e_fps, 3)
+        out["host_pageable_vs_end_to_end"] = round(rates["host_pageable_fps"] / e2e_fps, 3)
+    return out
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+# ---------------------------------------------------------------------------
+# workload c1 = BASELINE.json configs[0]: the reference's own config.json on a short 1080p clip, through the
+# reference-shaped entry points.
+# ---------------------------------------------------------------------------
+C1_CONFIG = {"crf": 23, "resize_width": 64, "resize_height": 64, "frame_interval": 10, "batch_size": 100}  # /root/reference/config.json
+
+
+def _c1_quality_item(pair):
+    from oracle import pipeline as pl
+    from rtvqa_amd.engine import bgr_planes
+    ref, dist = pair
+    return pl.frame_quality(ref, dist, bgr_planes(ref.shape[0], ref.shape[1]), "gauss")
+
+
+def c1_clip(rank, h, w, n):
+    from rtvqa_amd import synth
+    parts = [stream_chunk("natural", rank, h, w, a, min(CHUNK, n - a)) for a in range(0, n, CHUNK)]
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
+def c1_oracle(ref, dist, workers, pool=True):
+    """The reference's two calls on the clip, restated on the CPU: the quality filters over every frame pair (the ffmpeg
+    subprocess of video_processing.py:270-297 - here the oracle's PSNR/SSIM under the same process pool) and
+    calculate_average_scene_complexity with its own dispatcher (a NEW pool per metric pass, complexity_metrics.py:143).
+    -> (8-tuple, [(sse, ssim)] per frame)"""
+    from concurrent.futures import ProcessPoolExecutor
+    from oracle import pipeline as pl
+    cfg = C1_CONFIG
+    items = [(ref[i], dist[i]) for i in range(len(ref))]
+    if pool:
+        q = []
+        with ProcessPoolExecutor(max_workers=workers) as ex:
+            for i in range(0, len(items), 100):
+                q.extend(ex.map(_c1_quality_item, items[i:i + 100]))
+    else:
+        q = [_c1_quality_item(it) for it in items]
+    tup = pl.calculate_average_scene_complexity(list(dist), cfg["resize_width"], cfg["resize_height"], cfg["frame_interval"],
+                                                num_workers=workers, batch_size=cfg["batch_size"], dct_mode="full",
+                                                dispatcher=pl.process_in_batches if pool else pl.serial_map)
+    return tup, q
+
+
+def cpu_baseline_c1(ref, dist):
+    """ref/dist: the clip or its first frames (0.35 s of CPU work per frame pair for PSNR/SSIM, 0.36 s per selected frame
+    for the complexity suite: the 300-frame clip is ~115 s of CPU work spread over the pool)"""
+    from oracle import c_oracle as co
+    co.build()
+    cores = visible_cores()
+    workers, override = cpu_workers(cores)
+    sample = len(ref)
+    t0 = time.perf_counter()
+    tup, q = c1_oracle(ref, dist, workers)
+    dt = time.perf_counter() - t0
+    return (sample, tup, q), dict(value=round(sample / dt, 3), unit="frames/s", cores=cores, workers=workers, workers_override=override,
+                                  cgroup_cpu_limit=cgroup_cpu_limit(), kind="port", seconds=round(dt, 2),
+                                  sample="the first %d frames of the same clip through oracle/pipeline.py: PSNR/SSIM of every frame "
+                                         "pair under ProcessPoolExecutor(max_workers=cores//2 = %d of %d visible cores), then "
+                                         "calculate_average_scene_complexity with the reference's dispatcher (a new pool per "
+                                         "metric pass, chunksize 1, batch_size 100)" % (sample, workers, cores))
+
+
+def main_c1(args, rank, local_rank, world):
+    wl = WORKLOADS["c1"]
+    h, w = wl["h"], wl["w"]
+    n = args.batch or wl["batch"]
+    cfg = dict(C1_CONFIG)
+    if args.stub_engine:
+        raise SystemExit("--stub-engine rehearses the rank logic of the C-ABI workloads; c1 has no stub")
+    # ---- CPU first (its pools fork before this process touches the GPU): baseline on rank 0 at N = 1, and the expectation
+    expect, cpu_line = None, None
+    ref_h, dist_h = c1_clip(rank, h, w, n)  # ordinary host arrays: what a caller that decoded two files holds
+    if world == 1 and rank == 0 and args.cpu_sample != 0:
+        ns = min(n, args.cpu_sample if args.cpu_sample > 0 else n)  # default: the WHOLE clip (300 frames: ~105 s of CPU work over the pool)
+        expect, cpu_line = cpu_baseline_c1(ref_h[:ns], dist_h[:ns])
+    elif args.verify:
+        nv = min(n, 30)
+        expect = (nv,) + c1_oracle(ref_h[:nv], dist_h[:nv], 1, pool=False)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    rehearsal = "VQA_BENCH_DEVICE" in os.environ
+    device = int(os.environ.get("VQA_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device)
+    os.environ["VQA_DEVICE"] = str(device)  # the entry points' default engine (stream.get_engine)
+    dist_on = world > 1 or args.dist_always
+    td, backend_used, red_dev, rccl_ranks = None, None, "cpu", None
+    if dist_on:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        td, backend_used, red_dev, rccl_ranks = init_dist(args.backend, rank, world, device, rehearsal, False)
+
+    import rtvqa_amd
+    from rtvqa_amd import _native as N
+    from rtvqa_amd import complexity_metrics as cm
+    from rtvqa_amd import stream, synth
+    from rtvqa_amd import video_processing as vp
+    from rtvqa_amd.engine import bgr_planes
+    eng = cm.get_engine(device)
+    ref_pin, dist_pin = eng.alloc_pinned((n, h, w, 3)), eng.alloc_pinned((n, h, w, 3))
+    ref_pin[...] = ref_h
+    dist_pin[...] = dist_h
+    ref_dev, dist_dev = eng.upload(ref_pin), eng.upload(dist_pin)
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="vqa_c1_")
+    csv = os.path.join(tmp, "c1.csv")
+
+    def step():
+        return vp.process_video_and_extract_metrics(ref_dev, dist_dev, cfg, csv_file=csv)
+
+    def fence():
+        for e in stream.get_engine_pair(device):
+            e.sync()
+        torch.cuda.synchronize()
+        if dist_on:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    metrics = None
+    for _ in range(max(args.warmup, 1)):
+        metrics = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        metrics = step()
+    fence()
+    dt = time.perf_counter() - t0
+
+    # ---- serial pass for the per-kernel table: the same pass on ONE context, overlap off, HIP-event profiling on
+    planes = bgr_planes(h, w)
+    prof, dt_serial = {}, None
+    if args.serial_pass and args.steps > 0:
+        eng.set_overlap(False)
+        qual = stream.Quality(planes, N.SSIM_GAUSS)
+        cx = stream.Complexity((cfg["resize_width"], cfg["resize_height"]), cfg["frame_interval"])
+        stream.run(dist_dev, ref_dev, qual, cx, cfg["batch_size"], engine=eng)
+        eng.profile(True)
+        eng.profile_read(reset=True)
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            stream.run(dist_dev, ref_dev, qual, cx, cfg["batch_size"], engine=eng)
+        eng.sync()
+        dt_serial = time.perf_counter() - ts
+        prof = eng.profile_read(reset=True)
+        eng.profile(False)
+        eng.set_overlap(True)
+
+    # ---- verification: the entry points on the first nv frames against the oracle's numbers for those frames
+    verified = None
+    if args.verify and expect is not None:
+        nv, tup, q = expect
+        bad = []
+        got = cm.calculate_average_scene_complexity(dist_dev.slice(0, nv), cfg["resize_width"], cfg["resize_height"],
+                                                    frame_interval=cfg["frame_interval"], batch_size=cfg["batch_size"])
+        for k, (g, wv) in enumerate(zip(got, tup)):
+            g, wv = float(g), float(wv)
+            tol = 1e-12 if k in (2, 3, 4, 5, 7) else 1e-4   # counts + the reference's own NumPy tails | DCT, motion floats
+            if not ((g != g and wv != wv) or abs(g - wv) <= tol * max(abs(wv), 1e-30)):
+                bad.append("tuple[%d] %.12g vs %.12g" % (k, g, wv))
+        sse, ssim, _sizes = vp.frame_quality(ref_dev.slice(0, nv), dist_dev.slice(0, nv))
+        for i, (es, em) in enumerate(q):
+            if [int(v) for v in sse[i]] != [int(v) for v in es]:
+                bad.append("frame %d sse %s != %s" % (i, sse[i].tolist(), es))
+            if any(abs(float(a) - float(b)) > 1e-4 * abs(float(b)) for a, b in zip(ssim[i], em)):
+                bad.append("frame %d ssim %s vs %s" % (i, ssim[i].tolist(), em))
+        # the row the timed call returned: first-frame PSNR / SSIM as the stats files print them
+        es, em = q[0]
+        mse = sum(es) / (3.0 * h * w)
+        if abs(metrics["PSNR"] - 10.0 * np.log10(255.0 ** 2 / mse)) > 6e-3 or abs(metrics["SSIM"] - sum(em) / 3.0) > 1e-4:
+            bad.append("row PSNR/SSIM %r %r" % (metrics["PSNR"], metrics["SSIM"]))
+        verified = {"frames": nv, "ok": not bad, "checker": "oracle/pipeline.py on the first %d frames of the clip (computed before GPU init)" % nv,
+                    "fields": "8-tuple: histogram/edge/orb/colour-histogram/frame-rate slots 1e-12 (exact counts + the reference's NumPy "
+                              "tails), motion/dct/temporal 1e-4; per frame: sse exact, ssim 1e-4; the CSV row's PSNR/SSIM"}
+        if bad:
+            sys.stderr.write("[bench] rank %d: FATAL: c1 output differs from the oracle: %s\n" % (rank, json.dumps(bad[:8])))
+            sys.stderr.flush()
+        if dist_on:
+            nbad = torch.tensor([float(len(bad))], dtype=torch.float64, device=red_dev)
+            td.all_reduce(nbad, op=td.ReduceOp.SUM)
+            if nbad.item() > 0:
+                os._exit(4)
+        elif bad:
+            os._exit(4)
+
+    dt, devices = reduce_over_ranks(td if dist_on else None, dt, [float(metrics.get("SSIM", 0.0)), float(metrics["DCT Complexity"]), float(n)],
+                                    device, world, rehearsal, False, red_dev)
+    value = n * args.steps * world / dt if args.steps > 0 else 0.0
+    if rank == 0:
+        P = h * w
+        fpl = float(n) / max(1, -(-n // cfg["batch_size"]))  # frame pairs per quality launch (chunks of batch_size)
+        alg = {"k_ssim_gauss": int(6 * P * fpl)}
+        kernels, roof = kernel_report(prof, alg, {"k_ssim_gauss": int(88 * P * 3 * fpl)}, {}, "c1", fpl, False)
+        line = {"metric": "frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": max(args.warmup, 1), "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
+                "ms_per_step_serial": round(dt_serial / args.steps * 1e3, 4) if dt_serial else None,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->f32 (SSE/bins/SAD exact int)",
+                "data": "synthetic (synth.s_natural v%d, seed 1234, one %d-frame clip per GPU; distorted = +-3 grey levels)"
+                        % (synth.GENERATOR_VERSION, n),
+                "config": {"workload": wl["name"], "id": "c1", "frames_per_step_per_gpu": n, "reference_config": cfg,
+                           "selected_frames": len(cm.selected_indices(n, cfg["frame_interval"])),
+                           "entry_point": "rtvqa_amd.video_processing.process_video_and_extract_metrics",
+                           "collective": ("%s scalar all-reduce" % ("rccl" if backend_used == "nccl" else "gloo")) if dist_on else "none",
+                           "backend": backend_used, "rccl_ranks": rccl_ranks, "devices": devices, "resident": "HBM",
+                           "ssim_mode": "gauss", "pixfmt": "bgr24", "dct_mode": "auto (full-frame at 64x64, as cv2.dct)",
+                           "motion": "sad", "parallelism": "1 clip/GPU x%d" % world},
+                "roofline": roof, "kernels": kernels,
+                "serial": {"ms_per_step": round(dt_serial / args.steps * 1e3, 4), "fps": round(n * args.steps / dt_serial, 1),
+                           "what": "the same pass (stream.run) on ONE context, VQA_OPT_OVERLAP off, HIP-event profiling on"} if dt_serial else None,
+                "row": {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in metrics.items()
+                        if k in ("PSNR", "SSIM", "Resolution (px)")}}
+        if args.api_steps > 0:
+            rates, _m = api_rates(vp, cm, {"host_pinned": (ref_pin, dist_pin), "host_pageable": (ref_h, dist_h)}, cfg, args.api_steps, n)
+            line["api_end_to_end"] = dict(rates, resident_fps=round(value / world, 1), frames_per_call=n, calls=args.api_steps,
+                                          bytes_per_frame=2 * 3 * P,
+                                          note="the same call from host memory: both 1080p streams cross PCIe once (12.4 MB per frame "
+                                               "pair), the complexity kernels read every 10th frame of the uploaded chunk")
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
+        if verified is not None:
+            line["verified"] = verified
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        td.barrier()
+        td.destroy_process_group()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    cm.release_buffers()
+
+
+# ---------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +719,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frame pairs for the CPU baseline (0 = skip, -1 = auto)")
     ap.add_argument("--e2e-steps", type=int, default=6, help="steps of the PCIe-inclusive end_to_end measurement (0 = skip)")
     ap.add_argument("--e2e-batch", type=int, default=64, help="frames per step of the end_to_end measurement")
+    ap.add_argument("--api-steps", type=int, default=3,
+                    help="timed calls per residence of the api_end_to_end measurement (the reference-shaped Python entry point on "
+                         "the workload's clip; full-suite workloads in their default modes only; 0 = skip)")
+    ap.add_argument("--dist-always", action="store_true",
+                    help="initialise torch.distributed (and run every collective of the N > 1 path) even when WORLD_SIZE is 1: "
+                         "the one-rank RCCL bring-up a 1-GPU box can execute")
     ap.add_argument("--ssim-mode", default=None, choices=["gauss", "ffmpeg"], help="default: gauss (c3ref: ffmpeg)")
     ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
                     help="1 (default): quality and complexity kernels of a batch on one context; 2: the quality kernels on a "
@@ -407,6 +777,8 @@ def main():
 
     # CPU baseline first: its worker processes are forked before this process touches the GPU.  The same leg
     # computes the oracle's expected records for a few frames of this rank's stream (the checker of "verified").
+    if args.workload == "c1":
+        return main_c1(args, rank, local_rank, world)
     cpu_line, expect = None, {}
     yuv = args.pixfmt == "yuv420p"
     if not stub and args.verify and args.steps > 0:
@@ -429,9 +801,12 @@ def main():
             raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
         # VQA_BENCH_DEVICE pins every rank to one device: only for rehearsing the N > 1 logic on a 1-GPU box
         torch.cuda.set_device(device)
-    dist_on = world > 1
+    dist_on = world > 1 or args.dist_always
     td, backend_used, red_dev, rccl_ranks = None, None, "cpu", None
     if dist_on:
+        if world == 1:  # --dist-always without a launcher: a rendezvous of one
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         td, backend_used, red_dev, rccl_ranks = init_dist(args.backend, rank, world, device, rehearsal, stub)
 
     def sync_device():
@@ -477,10 +852,13 @@ def main():
         if yuv:
             yref_buf, ydist_buf = DeviceBuffer(eng, ybytes * (B + 1)), DeviceBuffer(eng, ybytes * (B + 1))
         do_e2e = rank == 0 and args.e2e_steps > 0
+        default_modes = (args.ssim_mode == "gauss" and not yuv and args.motion == "sad" and args.dct_mode == "block8")
+        do_api = rank == 0 and args.api_steps > 0 and full and default_modes
         Be = min(args.e2e_batch, B)
+        Bh = B if do_api else Be  # host copies: the whole clip for the API legs, else the end_to_end batch
         yref_pin = ydist_pin = None
-        if do_e2e:  # page-locked host copies of the first Be+1 frames for the end_to_end measurement
-            ref_pin, dist_pin = eng.alloc_pinned((Be + 1, h, w, 3)), eng.alloc_pinned((Be + 1, h, w, 3))
+        if do_e2e or do_api:  # page-locked host copies of the first Bh+1 frames (end_to_end reads the first Be+1 of them)
+            ref_pin, dist_pin = eng.alloc_pinned((Bh + 1, h, w, 3)), eng.alloc_pinned((Bh + 1, h, w, 3))
             if yuv:  # the quality kernels' planar inputs cross PCIe too (the reference stream only in that form)
                 yref_pin, ydist_pin = eng.alloc_pinned((Be + 1, ybytes)), eng.alloc_pinned((Be + 1, ybytes))
         for a in range(0, B + 1, CHUNK):
@@ -493,10 +871,12 @@ def main():
                 N.check(eng.lib.vqa_copy_h2d(eng.ctx, yref_buf.ptr + a * ybytes, yr.ctypes.data, yr.nbytes), "h2d", eng.ctx)
                 N.check(eng.lib.vqa_copy_h2d(eng.ctx, ydist_buf.ptr + a * ybytes, yd.ctypes.data, yd.nbytes), "h2d", eng.ctx)
             eng.sync()
-            if do_e2e and a <= Be:
-                m = min(n, Be + 1 - a)
+            if (do_e2e or do_api) and a <= Bh:
+                m = min(n, Bh + 1 - a)
                 ref_pin[a:a + m] = r[:m]
                 dist_pin[a:a + m] = d[:m]
+            if do_e2e and a <= Be:
+                m = min(n, Be + 1 - a)
                 if yuv:
                     yref_pin[a:a + m] = yr[:m].reshape(m, ybytes)
                     ydist_pin[a:a + m] = yd[:m].reshape(m, ybytes)
@@ -625,21 +1005,9 @@ def main():
             os._exit(4)  # no JSON line for a run whose output is wrong
 
     # ---- max over ranks, and the one scalar all-reduce the path has (pooled metrics)
-    devices = [device]
-    if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-        dt = float(tmax.item())
-        pooled = torch.tensor([float(q["ssim"].mean()) if q is not None else 0.0,
-                               float(c["dct_energy"].mean()) if c is not None else 0.0, float(B)],
-                              dtype=torch.float64, device=red_dev)
-        td.all_reduce(pooled, op=td.ReduceOp.SUM)  # RCCL over xGMI: 24 bytes, latency-bound
-        seen = [None] * world
-        td.all_gather_object(seen, device)
-        devices = sorted(set(int(x) for x in seen))
-        if not rehearsal and not stub and len(devices) != world:
-            sys.stderr.write("[bench] FATAL: %d ranks share %d devices %s\n" % (world, len(devices), devices))
-            os._exit(3)
+    dt, devices = reduce_over_ranks(td if dist_on else None, dt, [float(q["ssim"].mean()) if q is not None else 0.0,
+                                                                  float(c["dct_energy"].mean()) if c is not None else 0.0, float(B)],
+                                    device, world, rehearsal, stub, red_dev)
     frames_total = B * args.steps * world
     value = frames_total / dt if args.steps > 0 else 0.0
 
@@ -653,8 +1021,8 @@ def main():
         config = {"workload": wl["name"] if args.ssim_mode == "gauss" else
                   wl["name"].replace("SSIM(gauss 11x11)", "SSIM(FFmpeg vf_ssim 8x8 integer)"),
                   "id": args.workload, "frames_per_step_per_gpu": B, "streams": args.streams, "inflight": args.inflight,
-                  "collective": ("%s scalar all-reduce" % ("rccl" if backend_used == "nccl" else "gloo")) if world > 1 else "none",
-                  "rccl_ranks": rccl_ranks, "devices": devices, "rehearsal_single_device": bool(rehearsal and world > 1),
+                  "collective": ("%s scalar all-reduce" % ("rccl" if backend_used == "nccl" else "gloo")) if dist_on else "none",
+                  "backend": backend_used, "rccl_ranks": rccl_ranks, "devices": devices, "rehearsal_single_device": bool(rehearsal and world > 1),
                   "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode,
                   "motion": args.motion, "parallelism": "1 stream/GPU x%d" % world,
                   "overlap": bool(args.overlap)}
@@ -681,7 +1049,7 @@ def main():
                 # (the magnitude is summed by the last iteration; rounds 2-3, products through HBM: 440 B)
                 "farneback(pyramid)": 279 * P * B,
             }
-            def _smooth(n):  # the library's rule (k_dct_fft.hip, dct_fft_factor): even, 128..4096, prime factors 2, 3, 5
+            def _smooth(n):  # the library's rule (k_dct_fft.hip, dct_fft_factor): even, 128..4000, prime factors 2, 3, 5
                 if n < 128 or n > 4000 or n % 2:
                     return False
                 for q in (2, 3, 5):
@@ -694,32 +1062,14 @@ def main():
                 alg_bytes["k_dct_full"] = 18 * P * B
             else:
                 mfma_flops = {"k_dct_full": 2 * 2.0 * (w * w * h + h * h * w) * B}  # energy + temporal, 2 dense products each
-            kernels = {}
-            for name, (ms, cnt) in prof.items():
-                per = ms / cnt
-                ent = {"ms_per_launch": round(per, 4), "launches": cnt, "share_of_kernel_time": 0.0}
-                if name in alg_bytes:
-                    gbs = alg_bytes[name] / (per * 1e-3) / 1e9
-                    ent.update({"alg_bytes": alg_bytes[name], "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)})
-                kernels[name] = ent
-            tot = sum(ms for ms, _ in prof.values()) or 1.0
-            for name, (ms, _) in prof.items():
-                kernels[name]["share_of_kernel_time"] = round(ms / tot, 4)
-            if "k_dct8" in kernels:
-                kernels["k_dct8"]["unfused_alg_bytes"] = 3 * P * B
             # fp32 vector work of the Gaussian SSIM: separable 11+11 taps on 4 moment maps = 88 FMA per pixel and plane
             # (DESIGN.md section 5); the vector-ALU peak is 157.3 TFLOP/s (MI355X_MICROARCH.md)
             valu_fma = {"k_ssim_gauss": 88 * P * B * 3 if not yuv else int(88 * 1.5 * P * B / 2)}
-            for name, fma in valu_fma.items():
-                if name in kernels:
-                    tf = 2.0 * fma / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
-                    kernels[name].update({"fma": fma, "TFLOPps": round(tf, 1), "frac_fp32": round(tf / 157.3, 4)})
-            for name, fl in mfma_flops.items():
-                if name in kernels:
-                    tf = fl / (kernels[name]["ms_per_launch"] * 1e-3) / 1e12
-                    kernels[name].update({"flops": fl, "TFLOPps": round(tf, 1), "frac_mfma_f32": round(tf / 157.3, 4)})
-            cands = [k for k in prof if k in alg_bytes or k in mfma_flops]
-            dom = max(cands, key=lambda k: prof[k][0]) if cands else None
+            default_mode = (args.ssim_mode == "gauss" and not yuv and args.content == "natural" and args.motion == "sad"
+                            and args.dct_mode == "block8")  # (the PMC passes profile the serial pass's launches)
+            kernels, roof = kernel_report(prof, alg_bytes, valu_fma, mfma_flops, args.workload, B, default_mode)
+            if "k_dct8" in kernels:
+                kernels["k_dct8"]["unfused_alg_bytes"] = 3 * P * B
             serial = None
             if dt_serial:
                 sum_ms = sum(ms for ms, _ in prof.values()) / args.steps
@@ -727,39 +1077,17 @@ def main():
                           "fps": round(B * args.steps / dt_serial, 1),
                           "what": "the same steps on ONE context, VQA_OPT_OVERLAP off, HIP-event profiling on, after the "
                                   "timed region: the source of `kernels` and `roofline` (event times free of GPU sharing)"}
-            if dom is None:
-                roof = None
-            elif dom in mfma_flops:
-                roof = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": 157.3, "unit": "TFLOP/s",
-                        "frac": kernels[dom]["frac_mfma_f32"], "traffic": None, "traffic_source": "none",
-                        "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32); achieved = flops per launch / mean HIP-event duration"}
-            else:
-                default_mode = (args.ssim_mode == "gauss" and not yuv and args.content == "natural" and args.motion == "sad"
-                                and args.dct_mode == "block8")  # (the PMC passes profile the serial pass's launches)
-                traffic, tsrc = pmc_traffic(args.workload, dom, B, default_mode)
-                if kernels[dom]["frac_hbm"] < 0.2 and "frac_fp32" in kernels[dom]:
-                    # a kernel this far below the HBM roof that does counted fp32 work is reported against the roof it
-                    # really has: the vector ALUs; the HBM figures stay beside it
-                    roof = {"bound": "valu_fp32", "kernel": dom, "achieved": kernels[dom]["TFLOPps"], "peak": 157.3,
-                            "unit": "TFLOP/s", "frac": kernels[dom]["frac_fp32"], "fma": kernels[dom]["fma"],
-                            "frac_hbm": kernels[dom]["frac_hbm"], "achieved_hbm_GBps": kernels[dom]["GBps"],
-                            "peak_hbm_GBps": HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                            "alg_bytes": alg_bytes[dom],
-                            "note": "achieved = 2 x 88 FMA per pixel and plane / mean HIP-event duration; fp32 vector peak "
-                                    "157.3 TFLOP/s at 2.4 GHz; the kernel issues packed FMAs at the calibrated rate "
-                                    "(DESIGN.md 4b/5) and the chip holds ~1.9 GHz under it (profiles/round*_clock.json); "
-                                    "frac_hbm = algorithmic bytes / time / 8 TB/s is kept for the HBM view"}
-                else:
-                    roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": traffic, "traffic_source": tsrc,
-                            "alg_bytes": alg_bytes[dom],
-                            "note": "achieved = algorithmic bytes per launch / mean HIP-event duration of that launch"}
             line.update({"data": "synthetic (synth.s_%s v%d, seed 1234, one stream per GPU; distorted = +-3 grey levels)"
                                  % (args.content, synth.GENERATOR_VERSION),
                          "config": config, "roofline": roof, "kernels": kernels, "serial": serial})
             if do_e2e:
-                line["end_to_end"] = end_to_end(rtvqa_amd, N, device, eng, ref_pin, dist_pin, h, w, full, mask, params,
-                                                planes, smode, args.e2e_steps, yref_pin, ydist_pin)
+                line["end_to_end"] = end_to_end(rtvqa_amd, N, device, eng, ref_pin[:Be + 1], dist_pin[:Be + 1], h, w, full, mask,
+                                                params, planes, smode, args.e2e_steps, yref_pin, ydist_pin)
+            if do_api:
+                line["api_end_to_end"] = api_end_to_end(rtvqa_amd, eng, ref_all, dist_all, ref_pin, dist_pin, h, w, args.api_steps,
+                                                        value, line.get("end_to_end", {}).get("fps"))
+            elif rank == 0 and args.api_steps > 0:
+                line["api_end_to_end"] = None  # (c2 / non-default modes: process_video_and_extract_metrics runs the default full suite)
             if cpu_line is not None:
                 line["cpu_baseline"] = cpu_line
             if verified is not None:

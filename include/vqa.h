@@ -44,7 +44,7 @@
  * honours VQA_LIB_PATH to load another build of this ABI, and VQA_DEVICE.)  A separate
  * LAB build (`make -C csrc lab` -> lab/libvqa_hip_lab.so, vqa_build_flavour() != 0)
  * keeps superseded kernels and test seams behind VQA_*_VARIANT / VQA_COMM_FAKE_RCCL /
- * VQA_HYST_MAX_ROUNDS / VQA_FAIL_ENSURE_AT; it is for re-measurement and fault
+ * VQA_HYST_MAX_ROUNDS / VQA_FAIL_ENSURE_AT / VQA_FB_CHUNK_BYTES; it is for re-measurement and fault
  * injection only and is never loaded by default.
  */
 #ifndef VQA_H

@@ -54,6 +54,7 @@ struct vqa_ctx {
     int seam_hyst_max_rounds = 0;   // VQA_HYST_MAX_ROUNDS: the hysteresis tail's round bound (0 = the shipped bound)
     long seam_fail_at = 0;          // VQA_FAIL_ENSURE_AT=N: the N-th scratch reservation of this ctx reports VQA_ERR_OOM
     long seam_ensure_calls = 0;
+    long long seam_fb_chunk_bytes = 0; // VQA_FB_CHUNK_BYTES: Farneback's scratch budget per chunk (0 = the shipped 12 GiB): lets a small batch span chunks
 
     // device scratch (grow-only)
     dbuf gray_full, planeA, planeB, state, res_dev, partials, tile_flags, dirty0, dirty1, again_dev;
@@ -557,6 +558,7 @@ static int run_farneback(vqa_ctx *c, hipStream_t st, const uint8_t *gray, int gp
     dbuf *const fb_bufs[] = {&c->fb_tmp, &c->fb_blur, &c->fb_img, &c->fb_R, &c->fb_M, &c->fb_flow0, &c->fb_flow1, &c->fb_part};
     const size_t per_pair = (size_t)(two_kernel ? 72 : 59) * P;
     size_t budget = 12ull << 30;
+    if (c->seam_fb_chunk_bytes > 0) budget = (size_t)c->seam_fb_chunk_bytes; // (lab build only: never set in the shipped library)
     {
         size_t free_b = 0, total_b = 0, held = 0;
         for (dbuf *b : fb_bufs) held += b->cap;
@@ -749,6 +751,7 @@ int vqa_create(int device, vqa_ctx **out)
 #ifdef VQA_TEST_SEAMS
     if (const char *e = getenv("VQA_HYST_MAX_ROUNDS")) c->seam_hyst_max_rounds = atoi(e) > 0 ? atoi(e) : 0;
     if (const char *e = getenv("VQA_FAIL_ENSURE_AT")) c->seam_fail_at = atol(e);
+    if (const char *e = getenv("VQA_FB_CHUNK_BYTES")) c->seam_fb_chunk_bytes = atoll(e);
 #endif
     *out = c;
     return VQA_OK;

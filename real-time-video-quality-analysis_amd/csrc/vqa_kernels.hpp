@@ -10,7 +10,7 @@
 //   -DVQA_AB_VARIANTS  (make lab) additionally compiles the superseded kernels of earlier rounds and their VQA_*_VARIANT /
 //                      tuning selectors, for re-measurement (LAB_NOTES.md); results stay parity-tested.
 //   -DVQA_TEST_SEAMS   (make lab) additionally compiles the fault-injection / stand-in hooks the tests use:
-//                      VQA_COMM_FAKE_RCCL, VQA_HYST_MAX_ROUNDS, VQA_FAIL_ENSURE_AT.
+//                      VQA_COMM_FAKE_RCCL, VQA_HYST_MAX_ROUNDS, VQA_FAIL_ENSURE_AT, VQA_FB_CHUNK_BYTES.
 #ifdef VQA_AB_VARIANTS
 #include <cstdlib>
 #endif

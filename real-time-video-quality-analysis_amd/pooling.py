@@ -11,15 +11,15 @@ import numpy as np
 def smooth_data(data, alpha=0.8):
     """pandas ewm(alpha, adjust=True).mean():  y_t = sum_i (1-a)^i x_{t-i} / sum_i (1-a)^i."""
     x = np.asarray(data, dtype=np.float64).reshape(-1)
-    out = np.empty_like(x)
+    out = []
     num = 0.0
     den = 0.0
     decay = 1.0 - alpha
-    for i in range(x.size):
-        num = num * decay + x[i]
+    for v in x.tolist():  # Python floats are IEEE doubles: the same arithmetic as on NumPy scalars, five times faster
+        num = num * decay + v
         den = den * decay + 1.0
-        out[i] = num / den
-    return out
+        out.append(num / den)
+    return np.array(out, dtype=np.float64)
 
 
 def pooled_mean(data, alpha=0.8):

@@ -40,3 +40,11 @@ for th in (1, 2, 4, 8, 12):
     vp.process_video_and_extract_metrics(ref, dist, cfg, csv_file=csv)
     dt = time.perf_counter() - t0
     print("pageable, %2d copier threads: %6.0f frames/s" % (th, n / dt), flush=True)
+if os.environ.get("API_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5):
+        vp.process_video_and_extract_metrics(dev_r, dev_d, cfg, csv_file=csv)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(30)

@@ -889,13 +889,16 @@ _DRAIN_CODE = (
 
 
 @pytest.mark.parametrize("overlap", [1, 0])
-@pytest.mark.parametrize("fail_at", [1, 3, 4, 5, 6, 8, 10, 11, 14, 16, 20, 27])
+@pytest.mark.parametrize("fail_at", [1, 3, 4, 5, 6, 8, 10, 11, 12, 14, 15, 18, 20, 27, 32])
 def test_failed_submit_is_drained_and_the_context_stays_usable(fail_at, overlap):
-    """LAB build, VQA_FAIL_ENSURE_AT=N: the N-th scratch reservation of the context reports VQA_ERR_OOM.  A full-suite
-    complexity submit from host frames makes 10 reservations (1-2 staging, copies already enqueued behind them; 3 results;
-    4 gray planes; 5 DCT partials, gray + histogram kernels enqueued; 6-10 Canny's, AFTER the fork: block-SAD is then in
-    flight on a side stream), the quality submit 4 more (11-14); 15-28 are the same points of the second round, where
-    nothing is reallocated.  The failing submit must return the error with
+    """LAB build, VQA_FAIL_ENSURE_AT=N: the N-th device reservation of the context (scratch buffer or table array)
+    reports VQA_ERR_OOM.  A full-suite
+    complexity submit from host frames makes 14 reservations the first time (1-2 staging, copies already enqueued behind
+    them; 3 results; 4 gray planes; 5 DCT partials, gray + histogram kernels enqueued; 6-10 Canny's, AFTER the fork:
+    block-SAD is then in flight on a side stream; 11-14 the four arrays of ORB's resize table - a failure at 12 leaves
+    a half-built table, which must be freed and rebuilt by the next submit), the quality submit 4 more (15-18); from the
+    second round on the table is cached (10 + 4 per round: 19-32 ...) and nothing is reallocated.  The failing submit must
+    return the error with
     nothing pending and nothing in flight, and the SAME context must then return oracle-exact records, with the
     side-stream overlap on and off (video_processing.py:295-297: log, re-raise, nothing left running)."""
     import subprocess
@@ -905,6 +908,49 @@ def test_failed_submit_is_drained_and_the_context_stays_usable(fail_at, overlap)
     code = _DRAIN_CODE.replace("@OVERLAP@", str(overlap)) % REPO_ROOT
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=REPO_ROOT)
     assert r.returncode == 0 and "DRAIN-OK 1" in r.stdout, (fail_at, overlap, r.stdout[-300:], r.stderr[-1500:])
+
+
+_DRAIN_TABLES_CODE = (
+    "import sys, numpy as np; sys.path.insert(0, %r)\n"
+    "import rtvqa_amd\n"
+    "from rtvqa_amd import _native as N, synth\n"
+    "from oracle import c_oracle as co\n"
+    "h, w = 270, 480\n"
+    "fr = synth.s_natural(3, h, w, seed=23)\n"
+    "eng = rtvqa_amd.Engine(0)\n"
+    "assert eng.lib.vqa_build_flavour() & N.FLAVOUR_TEST_SEAMS\n"
+    "failed = 0\n"
+    "for attempt in range(3):\n"
+    "    try:\n"   # the full-frame DCT by FFT passes needs two plans of two device arrays each; Farneback three levels of tables
+    "        rec = eng.complexity(fr[1:], prev0=fr[0], mask=N.M_DCT | N.M_TEMPORAL_DCT | N.M_MOTION, dct_mode=N.DCT_FULL,\n"
+    "                             motion_mode=N.MOTION_FARNEBACK)\n"
+    "    except N.VqaError as e:\n"
+    "        assert e.status == N.VQA_ERR_OOM and 'test seam' in str(e), str(e)\n"
+    "        failed += 1\n"
+    "        eng._pending_c = None\n"
+    "        continue\n"
+    "    for i in range(2):\n"
+    "        g, gp = co.bgr2gray(fr[i + 1]), co.bgr2gray(fr[i])\n"
+    "        e, l1 = co.dct_energy_full(g), co.temporal_dct_full(gp, g)\n"
+    "        assert abs(rec[i]['dct_energy'] - e) <= 1e-4 * e and abs(rec[i]['temporal_dct_l1'] - l1) <= 1e-4 * l1, ('dct', attempt, i)\n"
+    "        f = co.farneback(gp, g)\n"
+    "        assert abs(rec[i]['flow_mag_mean'] - f) <= 1e-4 * f, ('flow', attempt, i)\n"
+    "print('DRAIN-OK', failed)\n"
+)
+
+
+@pytest.mark.parametrize("fail_at", [5, 6, 7, 8, 12, 17, 25])
+def test_half_built_tables_are_freed_and_rebuilt(fail_at):
+    """LAB build: the reservation that fails is one of a table set's arrays (the FFT plans' twiddle / post-twiddle pairs,
+    the Farneback pyramid's resize tables: uploads 5.. of this submit).  The set's earlier arrays must not leak into the
+    cache half-built: the failing submit reports the error, the next one rebuilds the set and is oracle-exact."""
+    import subprocess
+    import sys
+    from rtvqa_amd import _native as N
+    env = dict(os.environ, VQA_LIB_PATH=N.LAB_LIB_PATH, VQA_FAIL_ENSURE_AT=str(fail_at))
+    r = subprocess.run([sys.executable, "-c", _DRAIN_TABLES_CODE % REPO_ROOT], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=REPO_ROOT)
+    assert r.returncode == 0 and "DRAIN-OK 1" in r.stdout, (fail_at, r.stdout[-300:], r.stderr[-1500:])
 
 
 def test_hysteresis_overflow_is_flagged():
@@ -976,6 +1022,97 @@ def test_results_are_bit_identical_run_to_run(engine):
             assert (q["sse"].tobytes(), q["ssim"].tobytes()) == (q0["sse"].tobytes(), q0["ssim"].tobytes()), i
             if f is not None:
                 assert f["ssim"].tobytes() == f0["ssim"].tobytes(), i
+
+
+def test_farneback_and_full_dct_are_bit_identical_run_to_run_and_across_the_overlap_option(engine):
+    """The kernels with the hardest synchronisation - the fused Farneback iteration's one-barrier double-buffered LDS, the
+    in-place Stockham passes of the FFT-based full-frame DCT, the Farneback pre-passes piped onto a side stream through
+    events (with the chunk-seam wait) and the full-frame DCT forked onto its own stream - must return the same BYTES every
+    time: alone, next to a busy second context, and with VQA_OPT_OVERLAP on and off.  (Round 4's SSIM LDS race passed every
+    parity test and was caught only by a byte comparison.)  The chunk seam has its own test below."""
+    import rtvqa_amd
+    from rtvqa_amd import _native as N
+    fields = ("flow_mag_mean", "dct_energy", "temporal_dct_l1", "edge_count", "sad_sum")
+    params = engine.make_params(dct_mode=N.DCT_FULL, motion_mode=N.MOTION_FARNEBACK)
+
+    def run(d, n):
+        return engine.complexity(d.slice(1, n + 1), prev0=d.frame(0), mask=N.M_ALL, params=params)
+
+    def same(a, b):
+        return all(a[f].tobytes() == b[f].tobytes() for f in fields)
+
+    keep = engine.get_option(N.OPT_OVERLAP)
+    try:
+        # 1080p: FFT passes for the DCT (1080 = 2^3 3^3 5, 1920 = 2^7 3 5), one Farneback chunk
+        n = 6
+        d = engine.upload(_frames("natural", n + 1, 1080, 1920, seed=43))
+        engine.set_overlap(True)
+        base = run(d, n)
+        assert base["flow_mag_mean"].min() > 0 and base["temporal_dct_l1"].min() > 0
+        with rtvqa_amd.Engine(engine.device) as other:
+            po = other.make_params(dct_mode=N.DCT_BLOCK8)
+            for i in range(6):
+                engine.set_overlap(i % 2 == 0)
+                busy = i >= 2
+                if busy:
+                    other.complexity_submit(d.slice(1, n + 1), d.frame(0), N.M_ALL, po)
+                got = run(d, n)
+                if busy:
+                    other.complexity_wait()
+                assert same(got, base), (i, [f for f in fields if got[f].tobytes() != base[f].tobytes()])
+        d._owner.free()
+    finally:
+        engine.set_overlap(bool(keep))
+
+
+_FB_SEAM_CODE = (
+    "import sys, numpy as np; sys.path.insert(0, %r)\n"
+    "import rtvqa_amd\n"
+    "from rtvqa_amd import _native as N, synth\n"
+    "n, h, w = 23, 240, 426\n"
+    "fr = synth.s_noise(n + 1, h, w, seed=44)\n"
+    "fields = ('flow_mag_mean', 'dct_energy', 'temporal_dct_l1', 'edge_count')\n"
+    "out = []\n"
+    "with rtvqa_amd.Engine(0) as eng, rtvqa_amd.Engine(0) as other:\n"
+    "    assert eng.lib.vqa_build_flavour() & N.FLAVOUR_TEST_SEAMS\n"
+    "    d = eng.upload(fr)\n"
+    "    p = eng.make_params(dct_mode=N.DCT_FULL, motion_mode=N.MOTION_FARNEBACK)\n"
+    "    for i in range(6):\n"
+    "        eng.set_overlap(i %% 2 == 0)\n"
+    "        if i >= 2:\n"
+    "            other.complexity_submit(d.slice(1, n + 1), d.frame(0), N.M_ALL, other.make_params(dct_mode=N.DCT_BLOCK8))\n"
+    "        rec = eng.complexity(d.slice(1, n + 1), prev0=d.frame(0), mask=N.M_ALL, params=p)\n"
+    "        if i >= 2:\n"
+    "            other.complexity_wait()\n"
+    "        out.append(tuple(rec[f].tobytes() for f in fields))\n"
+    "assert all(o == out[0] for o in out), [k for k, o in enumerate(out) if o != out[0]]\n"
+    "np.save(sys.argv[1], np.frombuffer(out[0][0], np.float64))\n"
+    "print('SEAM-OK')\n"
+)
+
+
+def test_farneback_chunk_seam_is_bit_stable(tmp_path):
+    """A batch that spans Farneback chunks (LAB build, VQA_FB_CHUNK_BYTES shrinks the 12 GiB chunk budget so that 23 pairs of
+    240x426 take 1, 2 and 5 chunks): the side stream's pre-passes of chunk k + 1 wait for the iterations of chunk k through
+    an event.  With the overlap option on and off, alone and next to a busy context, one chunking always returns the same
+    bytes; different chunkings agree to 1e-6 on flow_mag_mean (the documented batch-geometry dependence, include/vqa.h)."""
+    import subprocess
+    import sys
+    from rtvqa_amd import _native as N
+    per_pair = 59 * 240 * 426
+    got = {}
+    for chunks, budget in ((1, 0), (2, per_pair * 12), (5, per_pair * 5)):
+        env = dict(os.environ, VQA_LIB_PATH=N.LAB_LIB_PATH)
+        if budget:
+            env["VQA_FB_CHUNK_BYTES"] = str(budget)
+        out = str(tmp_path / ("flow%d.npy" % chunks))
+        r = subprocess.run([sys.executable, "-c", _FB_SEAM_CODE % REPO_ROOT, out], env=env, capture_output=True, text=True,
+                           timeout=600, cwd=REPO_ROOT)
+        assert r.returncode == 0 and "SEAM-OK" in r.stdout, (chunks, r.stdout[-300:], r.stderr[-1500:])
+        got[chunks] = np.load(out)
+    assert got[1].min() > 0
+    for chunks in (2, 5):
+        assert np.allclose(got[chunks], got[1], rtol=1e-6, atol=0), chunks
 
 
 def test_region_of_interest_padded_rows(engine):
