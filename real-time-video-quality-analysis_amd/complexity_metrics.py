@@ -249,7 +249,8 @@ def process_in_batches(frames, process_func, num_workers, batch_size=100, **kwar
             call = functools.partial(process_func, **kwargs)
             results.extend(call(item) for item in batch)
             continue
-        rec = eng.complexity(np.stack(items), mask=_MASK[kind], resize=resize)
+        # the chunk in ONE pinned buffer (gathered by the copier threads), ONE asynchronous upload, ONE launch
+        rec = eng.complexity(stream.stage_frames(eng, items), mask=_MASK[kind], resize=resize)
         results.extend(_scalars(kind, rec))
     return results
 
@@ -265,13 +266,14 @@ def _motion_batch(eng, pairs):
     chained = all(pairs[live[k]][1] is pairs[live[k - 1]][0] for k in range(1, len(live))) and \
         live == list(range(live[0], live[0] + len(live)))
     if chained:
-        arr = np.stack([np.asarray(pairs[j][0]) for j in live])
-        rec = eng.complexity(arr, prev0=np.asarray(pairs[live[0]][1]), mask=N.M_MOTION, motion_mode=_motion_mode)
+        # (previous of the first pair, then every current frame) in one pinned buffer: slot 0 is the halo
+        arr = stream.stage_frames(eng, [np.asarray(pairs[live[0]][1])] + [np.asarray(pairs[j][0]) for j in live])
+        rec = eng.complexity(arr[1:], prev0=arr[0], mask=N.M_MOTION, motion_mode=_motion_mode)
         for j, v in zip(live, _scalars("motion", rec)):
             out[j] = v
     else:
         # arbitrary pairs: interleave (prev, curr) and keep every second result
-        arr = np.stack([np.asarray(pairs[j][s]) for j in live for s in (1, 0)])
+        arr = stream.stage_frames(eng, [np.asarray(pairs[j][s]) for j in live for s in (1, 0)])
         rec = eng.complexity(arr, mask=N.M_MOTION, motion_mode=_motion_mode)
         for j, v in zip(live, _scalars("motion", rec[1::2])):
             out[j] = v

@@ -10,22 +10,29 @@
 //                  4-byte-aligned planar planes and packed BGR24; the byte kernel is the general path for
 //                  every other layout (odd offsets / strides, other pixel steps) — not an A/B variant.
 //
-// k_ssim_gauss design.  The separable window needs 2 x 11 taps on 4 moment maps
-// (E[x], E[y], E[x^2+y^2], E[xy]) = 88 FMA per pixel, ~115 VALU ops per pixel
-// in total against 2 bytes of input: ~57 op/B where the chip balances at
-// 78.6 T lane-op/s / 8 TB/s ~ 10 op/B.  This kernel is VALU-bound by
-// construction; the design removes everything else:
-//   * every thread owns 2 adjacent columns and marches DOWN a strip of rows;
-//     the vertical pass is a rolling 11-slot accumulator file in registers
-//     (unrolled by 11 so slot indices are static): each input pixel is
-//     converted and multiplied once, there is no vertical halo recompute;
-//   * one vertically filtered row (4 maps) per step goes through LDS, split
-//     into even/odd column halves so every ds_read_b128 / ds_write_b128 is
-//     bank-conflict-free; the horizontal pass reads 12 columns for 2 outputs;
-//   * one barrier per row, LDS row double-buffered; next row's pixels are
-//     prefetched before the current row's arithmetic;
-//   * samples are centred (x-128) so the variance terms lose 4x less to fp32
-//     cancellation; SSE is exact integer arithmetic.
+// k_ssim_gauss design (the shipped kernel is k_ssim_gauss_p2<256, 8>, below).  The separable window needs 2 x 11
+// taps on 4 moment maps (E[x], E[y], E[x^2+y^2], E[xy]) = 88 FMA per pixel, ~115 VALU ops per pixel in total
+// against 2 bytes of input: ~57 op/B where the chip balances at 78.6 T lane-op/s / 8 TB/s ~ 10 op/B.  The kernel
+// is VALU-bound by construction (at 100 % of the fp32 vector peak it would reach 0.22 of the HBM roof); the design
+// removes everything else:
+//   * a workgroup of 256 threads owns 246 output columns of a strip of rows; every thread owns ONE input column
+//     and marches DOWN the strip.  The vertical pass is a rolling file of accumulators in registers - a ring of
+//     12 slots (11 live output rows + 1 spare so that the 8 rows of a step divide it), unrolled so slot indices
+//     are static: each input pixel is loaded (buffer_load_ubyte, scalar row offset), converted and multiplied
+//     once, there is no vertical halo recompute inside a strip;
+//   * 8 vertically filtered rows (4 maps, one float4 per column) go through LDS per round trip - a single buffer
+//     of 8 rows x 257 float4 (33 KB, 4 waves per SIMD) with two barriers per step (before the stores: the previous
+//     step's readers are done; before the reads).  For the horizontal pass a GROUP OF 8 LANES shares 8 adjacent
+//     columns: lane 8 j + i filters columns 8 j .. 8 j + 7 of the step's i-th row and reads the 18 columns
+//     8 j .. 8 j + 17 once (2.25 ds_read_b128 per output pixel instead of 11: LDS reads were 19 % of the launch's
+//     energy, and the kernel runs at the board's power limit - DESIGN.md section 5);
+//   * rows of the LDS buffer are 257 float4 apart, so the lanes of a group sit in different bank groups and every
+//     ds_read_b128 / ds_write_b128 is conflict-free; the next row's pixels are loaded before the current row's
+//     arithmetic;
+//   * samples are centred (x - 128) so the variance terms lose 4x less to fp32 cancellation; SSE is exact integer
+//     arithmetic (flushed from fp32 partial sums every <= 240 rows, while they are still exact).
+// The one-row-per-barrier kernel of rounds 1-3 (k_ssim_gauss, two adjacent columns per thread) survives only in
+// the lab build (VQA_SSIM_VARIANT), for re-measurement.
 // Algorithmic HBM bytes: 2P per plane pair.
 #include "vqa_dev.hpp"
 #include "vqa_kernels.hpp"
@@ -48,7 +55,6 @@ static inline int ssim_strips(int h, long long groups /* workgroups per strip ro
     const int cap = ssim_max_strips(h);
     return ns > cap ? cap : ns;
 }
-// rows a strip owns: a multiple of 11 (k_ssim_gauss consumes rows in groups of 11 and owns whole groups)
 #ifndef SSIM_ROWS
 #define SSIM_ROWS 8   // rows per LDS round trip of k_ssim_gauss_p2 (8 = shipped; 2, 4 = measurement builds)
 #endif
@@ -527,7 +533,7 @@ void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dis
     case 4: LAUNCH_SSIM(128, 2, 0); break;
     case 5: LAUNCH_SSIM(256, 2, 0); break; // round 3's shipped kernel (one row per barrier), with round 4's loop structure
 #endif
-    default: // the shipped kernel: two rows per barrier, lane pairs share the horizontal pass
+    default: // the shipped kernel: SSIM_ROWS = 8 rows per LDS round trip, groups of 8 lanes share the horizontal pass
         hipLaunchKernelGGL((k_ssim_gauss_p2<256, SSIM_ROWS>), dim3((bpp + 7) / 8 * 8 * count, n), dim3(256), 0, st, ref, dist, ref_frame_stride,
                            dist_frame_stride, g, pd.row_stride, pd.pixel_step, w, h, ncb, ns, QS, partials,
                            partial_plane_stride, n_planes, res);

@@ -191,6 +191,33 @@ def _upload(engine, dev_ptr, fb, copies, ring_frames=None):
                 engine.h2d_async(dev_ptr + (cp.slot + i) * fb, base + i * step, fb)
 
 
+def stage_frames(engine, items):
+    """A list of equally shaped uint8 frames -> ONE pinned array [n, ...] (process_in_batches' chunk: "whole batch staged
+    in one pinned buffer and dispatched as one launch").  The copier threads gather the frames straight
+    into a slot of the device's pinned ring - no intermediate np.stack.  Valid until the next pass / stage_frames call on
+    the device."""
+    shape = items[0].shape
+    for f in items:
+        if f.dtype != np.uint8:  # a silent cast would turn float frames in 0..1 into all-zero planes
+            raise ValueError("frames must be uint8 (got %s): decoded 8-bit BGR frames, as cv2.VideoCapture.read yields" % f.dtype)
+        if f.shape != shape:
+            raise ValueError("the frames of one launch must share a geometry (%s vs %s)" % (f.shape, shape))
+    fb = int(np.prod(shape, dtype=np.int64))
+    st = _staging_of(engine)
+    blk = st.ring(1, len(items) * fb)[0]
+    out = blk[:len(items) * fb].reshape((len(items),) + shape)
+    pool = st.copiers()
+    parts = min(STAGE_THREADS, len(items))
+
+    def gather(a, b):
+        for i in range(a, b):
+            np.copyto(out[i], items[i])
+    futs = [pool.submit(gather, len(items) * t // parts, len(items) * (t + 1) // parts) for t in range(parts)]
+    for f in futs:
+        f.result()
+    return out
+
+
 # ---------------------------------------------------------------------------
 # the pass
 # ---------------------------------------------------------------------------
