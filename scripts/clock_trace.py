@@ -58,8 +58,30 @@ def poll():
         time.sleep(0.05)
 
 
+def power_cap():
+    """What the box says its power limit is ("no power_cap_w read from the box is recorded anywhere"):
+    rocm-smi's view and the hwmon files of every amdgpu card, raw.  An ordinary user can read these; none is changed."""
+    out = {}
+    for flag in ("--showmaxpower", "--showpower"):
+        try:
+            r = subprocess.run([SMI, "-d", "0", flag, "--json"], capture_output=True, text=True, timeout=10)
+            out["rocm-smi " + flag] = (r.stdout or r.stderr).strip()[:600]
+        except Exception as e:
+            out["rocm-smi " + flag] = "error: %s" % e
+    import glob
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap*")
+                    + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")):
+        try:
+            out[f] = open(f).read().strip()
+        except Exception as e:
+            out[f] = "unreadable: %s" % e
+    return out
+
+
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
+    cap = power_cap()
+    print("power cap readout:", json.dumps(cap)[:800], flush=True)
     eng = rtvqa_amd.Engine(0)
     h, w, B = 1080, 1920, 256
     fb = h * w * 3
@@ -130,7 +152,7 @@ def main():
             summary[name]["power_w_median"], summary[name]["ms_per_iteration"]), flush=True)
     out = {"tool": "scripts/clock_trace.py", "sampler": SMI + " -d 0 --showclocks --showpower --json, every ~0.1-0.4 s",
            "workload": "256 x 1080p device-resident, synth.s_natural seed 1234", "seconds_per_phase": secs,
-           "summary": summary, "samples": [{k: v for k, v in x.items() if k != "raw"} for x in samples],
+           "power_cap_readout": cap, "summary": summary, "samples": [{k: v for k, v in x.items() if k != "raw"} for x in samples],
            "first_raw": next((x.get("raw") for x in samples if x.get("raw")), None)}
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(REPO, "gpurun_out", "clock_trace.json"), "w"), indent=1)

@@ -9,7 +9,7 @@ mkdir -p $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 # one counter per pass (collected together they come back mutually inconsistent on gfx950)
 for ctr in SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE; do
-  timeout -k 10 600 rocprofv3 --pmc $ctr --output-format csv -d $ROOT/gpurun_out/valu_${tag}_$ctr -- python3 $ROOT/bench.py "$@" --cpu-sample 0 --e2e-steps 0 --streams 1 --inflight 1 --no-overlap --no-serial-pass > $ROOT/gpurun_out/valu_${tag}_$ctr.log 2>&1 || { tail -5 $ROOT/gpurun_out/valu_${tag}_$ctr.log; exit 1; }
+  timeout -k 10 600 rocprofv3 --pmc $ctr --output-format csv -d $ROOT/gpurun_out/valu_${tag}_$ctr -- python3 $ROOT/bench.py "$@" --cpu-sample 0 --e2e-steps 0 --api-steps 0 --streams 1 --inflight 1 --no-overlap --no-serial-pass > $ROOT/gpurun_out/valu_${tag}_$ctr.log 2>&1 || { tail -5 $ROOT/gpurun_out/valu_${tag}_$ctr.log; exit 1; }
 done
 python3 - "$ROOT" "$tag" <<'PY'
 import collections, csv, glob, json, os, sys
