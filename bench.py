@@ -608,6 +608,10 @@ def main_c1(args, rank, local_rank, world):
     from rtvqa_amd import video_processing as vp
     from rtvqa_amd.engine import bgr_planes
     eng = cm.get_engine(device)
+    if args.inflight == 1:  # the serial configuration (profiling runs): every chunk on the one default engine, in order
+        stream.MAX_LANES = 1
+    for e in stream.get_engine_pair(device):
+        e.set_overlap(args.overlap)
     ref_pin, dist_pin = eng.alloc_pinned((n, h, w, 3)), eng.alloc_pinned((n, h, w, 3))
     ref_pin[...] = ref_h
     dist_pin[...] = dist_h
@@ -654,7 +658,7 @@ def main_c1(args, rank, local_rank, world):
         dt_serial = time.perf_counter() - ts
         prof = eng.profile_read(reset=True)
         eng.profile(False)
-        eng.set_overlap(True)
+        eng.set_overlap(args.overlap)
 
     # ---- verification: the entry points on the first nv frames against the oracle's numbers for those frames
     verified = None
@@ -713,7 +717,8 @@ def main_c1(args, rank, local_rank, world):
                            "collective": ("%s scalar all-reduce" % ("rccl" if backend_used == "nccl" else "gloo")) if dist_on else "none",
                            "backend": backend_used, "rccl_ranks": rccl_ranks, "devices": devices, "resident": "HBM",
                            "ssim_mode": "gauss", "pixfmt": "bgr24", "dct_mode": "auto (full-frame at 64x64, as cv2.dct)",
-                           "motion": "sad", "parallelism": "1 clip/GPU x%d" % world},
+                           "motion": "sad", "parallelism": "1 clip/GPU x%d" % world, "lanes": stream.MAX_LANES,
+                           "overlap": bool(args.overlap)},
                 "roofline": roof, "kernels": kernels,
                 "serial": {"ms_per_step": round(dt_serial / args.steps * 1e3, 4), "fps": round(n * args.steps / dt_serial, 1),
                            "what": "the same pass (stream.run) on ONE context, VQA_OPT_OVERLAP off, HIP-event profiling on"} if dt_serial else None,

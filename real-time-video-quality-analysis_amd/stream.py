@@ -35,6 +35,7 @@ from .pooling import shard_range
 
 CHUNK_BYTES_MAX = 1 << 30     # per chunk and stream on the device / in a ring slot (a chunk is at most batch_size frames)
 STAGE_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))  # copier threads of the pinned ring
+MAX_LANES = 2                 # engines a pass alternates its chunks between (1: everything on the default engine, in order)
 
 KINDS = ("motion", "dct", "hist", "edge", "orb", "color")
 MASK = {"dct": N.M_DCT, "temporal": N.M_TEMPORAL_DCT, "hist": N.M_GRAY_HIST, "color": N.M_COLOR_HIST,
@@ -288,7 +289,7 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
     chunks = [(a, min(a + cap, n)) for a in range(0, n, cap)] if want_q else [(j, min(j + cap, hi)) for j in range(lo, hi, cap)]
     # ---- lanes
     farneback = want_c and (complexity.mask & N.M_MOTION) and complexity.motion_mode == N.MOTION_FARNEBACK
-    if engine is not None or len(chunks) <= 1 or farneback:
+    if engine is not None or len(chunks) <= 1 or farneback or MAX_LANES < 2:
         lanes = [first]  # (Farneback keeps GiB-sized scratch per context and fills the chip on its own: one context)
     else:
         lanes = list(get_engine_pair(first.device))
