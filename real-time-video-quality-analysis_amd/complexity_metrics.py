@@ -51,10 +51,25 @@ def validate_video_path(input_path):
     raise ValueError("Unsupported file type. Please provide a .npy frame stack [N,H,W,3] (uint8, BGR).")
 
 
+def _from_torch(t):
+    """A PyTorch-ROCm tensor [N,H,W,3] uint8 (north_star: "decoded frames in pinned buffers (PyTorch-ROCm tensors ...)"):
+    on the GPU it is used in place (DeviceFrames.from_torch, zero-copy); on the host its memory is handed over as a NumPy
+    view - page-locked if the tensor was made with pin_memory=True, which the pass then DMAs from directly."""
+    if t.dtype.__str__() != "torch.uint8":
+        raise ValueError("frames must be uint8 (got %s)" % t.dtype)
+    if t.is_cuda:
+        return DeviceFrames.from_torch(t if t.is_contiguous() else t.contiguous())
+    return t.numpy()
+
+
 def _open_frames(video):
     """-> array-like [N,H,W,3] uint8 (np.ndarray, memmap or DeviceFrames)."""
     if isinstance(video, DeviceFrames):
         return video
+    if type(video).__module__.startswith("torch") and hasattr(video, "is_cuda"):
+        video = _from_torch(video)
+        if isinstance(video, DeviceFrames):
+            return video
     if isinstance(video, str):
         validate_video_path(video)
         if not os.path.isfile(video):

@@ -40,6 +40,11 @@ def _geometry(reference, layout, height, width):
 def _host_stream(a):
     if isinstance(a, DeviceFrames):
         return a
+    if type(a).__module__.startswith("torch") and hasattr(a, "is_cuda"):
+        from .complexity_metrics import _from_torch
+        a = _from_torch(a)
+        if isinstance(a, DeviceFrames):
+            return a
     a = np.asarray(a)
     if a.dtype != np.uint8:  # a silent cast would turn float frames in 0..1 into all-zero planes
         raise ValueError("frames must be uint8 (got %s)" % a.dtype)

@@ -1,0 +1,58 @@
+"""Differential soak of the one-pass host side (stream.run): random clip length / geometry / frame_interval / chunk size /
+residence (pageable, pinned, region of interest, memmap, device) and random halves (quality only, complexity only, fused) -
+every combination must return the bits of the one-chunk, one-engine pass over a contiguous copy of the clip.
+usage: python scripts/fuzz_stream.py [n_cases] [seed0]   (needs a GPU; exits non-zero on the first difference)"""
+import os, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from rtvqa_amd import complexity_metrics as cm, stream, synth
+from rtvqa_amd.engine import bgr_planes
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+eng = cm.get_engine()
+tmp = tempfile.mkdtemp(prefix="vqa_fuzz_")
+KINDS = ("motion", "dct", "hist", "edge", "orb", "color", "temporal")
+for case in range(n_cases):
+    r = np.random.default_rng(seed0 + case)
+    n, h, w = int(r.integers(1, 40)), int(r.integers(11, 120)), int(r.integers(11, 160))
+    iv, batch = int(r.integers(1, 7)), int(r.integers(1, 12))
+    rw, rh = (int(r.integers(8, 80)), int(r.integers(8, 80))) if case % 2 else (w, h)
+    ref = synth.s_natural(n, h, w, seed=case) if case % 3 else r.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    dist = synth.distort(ref)
+    res = int(r.integers(0, 5))
+    keep = []
+    if res == 0:
+        a, b = ref, dist
+    elif res == 1:
+        a, b = eng.alloc_pinned(ref.shape), eng.alloc_pinned(dist.shape)
+        a[...], b[...] = ref, dist
+        keep = [a, b]
+    elif res == 2:  # a region of interest inside larger frames (padded rows)
+        big_r, big_d = np.zeros((n, h + 5, w + 9, 3), np.uint8), np.zeros((n, h + 5, w + 9, 3), np.uint8)
+        big_r[:, 2:2 + h, 4:4 + w], big_d[:, 2:2 + h, 4:4 + w] = ref, dist
+        a, b = big_r[:, 2:2 + h, 4:4 + w], big_d[:, 2:2 + h, 4:4 + w]
+    elif res == 3:
+        np.save(os.path.join(tmp, "r.npy"), ref); np.save(os.path.join(tmp, "d.npy"), dist)
+        a, b = np.load(os.path.join(tmp, "r.npy"), mmap_mode="r"), np.load(os.path.join(tmp, "d.npy"), mmap_mode="r")
+    else:
+        a, b = eng.upload(ref), eng.upload(dist)
+    half = int(r.integers(0, 3))
+    q = stream.Quality(bgr_planes(h, w)) if half != 1 else None
+    cx = stream.Complexity((rw, rh), iv) if half != 0 else None
+    want_q, want_s = stream.run(dist, ref if q else None, q, cx, batch_size=10 ** 6, engine=eng)
+    got_q, got_s = stream.run(b, a if q else None, q, cx, batch_size=batch)
+    ctx = (case, n, h, w, iv, batch, rw, rh, res, half)
+    if q:
+        assert np.array_equal(got_q[0], want_q[0]) and np.array_equal(got_q[1], want_q[1]), ("quality", ctx)
+    if cx:
+        for k in KINDS:
+            assert len(got_s[k]) == len(want_s[k]) and all((x == y) or (x != x and y != y) for x, y in zip(got_s[k], want_s[k])), (k, ctx)
+    for p in keep:
+        eng.free_pinned(p)
+    if res == 4:
+        a._owner.free(); b._owner.free()
+    if case % 100 == 99:
+        print("case %d ok" % (case + 1), flush=True)
+        cm.release_buffers()
+print("fuzz_stream: %d cases, no difference" % n_cases)

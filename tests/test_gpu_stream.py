@@ -175,3 +175,30 @@ def test_release_buffers_then_the_api_still_works():
     a = cm.complexity_series(clip, 64, 64, 1, batch_size=4)
     cm.release_buffers()
     _same_series(cm.complexity_series(clip, 64, 64, 1, batch_size=4), a)
+
+
+def test_torch_tensors_are_accepted_in_place():
+    """north_star: the host holds decoded frames in pinned buffers - PyTorch-ROCm tensors.  A CUDA(HIP) uint8 tensor is used in
+    place (zero-copy DeviceFrames), a pin_memory CPU tensor is recognised as page-locked and DMA'd from directly; both give
+    the bits of the NumPy clip."""
+    import torch
+    from rtvqa_amd import complexity_metrics as cm
+    from rtvqa_amd import synth
+    from rtvqa_amd import video_processing as vp
+    ref = _clip(21, 96, 128, seed=61)
+    dist = synth.distort(ref)
+    want = cm.complexity_series(dist, 64, 64, 2, batch_size=4)
+    t_pin = torch.from_numpy(dist).pin_memory()
+    assert cm.get_engine().is_pinned(t_pin.numpy())
+    t_dev = torch.from_numpy(dist).cuda()
+    for src in (t_pin, t_dev, torch.from_numpy(dist)):
+        _same_series(cm.complexity_series(src, 64, 64, 2, batch_size=4), want)
+    t = cm.calculate_average_scene_complexity(t_dev, 64, 64, frame_interval=2)
+    t2 = cm.calculate_average_scene_complexity(dist, 64, 64, frame_interval=2)
+    assert all((a == b) or (a != a and b != b) for a, b in zip(t, t2))
+    with pytest.raises(ValueError):
+        cm.complexity_series(torch.zeros(3, 8, 8, 3), 8, 8, 1)
+    m = vp.process_video_and_extract_metrics(torch.from_numpy(ref).cuda(), t_dev, {"resize_width": 64, "resize_height": 64, "frame_interval": 2},
+                                             csv_file=os.devnull)
+    m2 = vp.process_video_and_extract_metrics(ref, dist, {"resize_width": 64, "resize_height": 64, "frame_interval": 2}, csv_file=os.devnull)
+    assert m["PSNR"] == m2["PSNR"] and m["SSIM"] == m2["SSIM"] and m["DCT Complexity"] == m2["DCT Complexity"]
