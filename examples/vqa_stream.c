@@ -1,0 +1,201 @@
+/* vqa_stream.c — the one-pass pipeline (the host side that real-time-video-quality-analysis_amd/stream.py is for the
+ * Python surface) from plain C against include/vqa.h alone: a clip of reference / encoded frames in ORDINARY (pageable)
+ * host memory is cut into chunks; copier threads gather chunk k+1 into a slot of a three-slot pinned ring while chunk k
+ * crosses PCIe (vqa_copy_h2d: a true DMA from pinned memory) and chunk k-1 is on the GPU; chunks alternate between two
+ * contexts (two HIP streams), each chunk is uploaded ONCE and serves both the quality kernels (every frame,
+ * video_processing.py:216) and the complexity kernels (every interval-th frame, a strided device view of the same bytes,
+ * video_processing.py:242 / complexity_metrics.py:103-104).
+ *
+ *   gcc -O2 -pthread -Iinclude -o vqa_stream examples/vqa_stream.c -Lreal-time-video-quality-analysis_amd/csrc -lvqa_hip \
+ *       -Wl,-rpath,$PWD/real-time-video-quality-analysis_amd/csrc -lm
+ *   ./vqa_stream [frames=120] [height=1080] [width=1920] [interval=10] [chunk=24] [copier threads=6]
+ *
+ * Self-check: the clip's frames repeat with period 2 * interval (from the second selected frame on), so every measured
+ * sample must carry the same records as the sample two steps earlier, and PSNR's SSE must be what the generator put in
+ * (ref vs ref + 1: one per pixel and plane).  Exit code 0 = every call succeeded and the checks hold. */
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "vqa.h"
+
+#define LANES 2
+#define SLOTS (LANES + 1)
+#define MAXT 16
+
+static vqa_ctx *g_err_ctx;
+#define CHECK(call)                                                                                                   \
+    do {                                                                                                              \
+        int rc_ = (call);                                                                                             \
+        if (rc_ != VQA_OK) {                                                                                          \
+            fprintf(stderr, "%s -> %s (%s)\n", #call, vqa_strerror(rc_), g_err_ctx ? vqa_last_hip_error(g_err_ctx) : ""); \
+            return 2;                                                                                                 \
+        }                                                                                                             \
+    } while (0)
+
+typedef struct { uint8_t *dst; const uint8_t *src; size_t bytes; } copy_job;
+
+static void *copier(void *arg)
+{
+    copy_job *j = (copy_job *)arg;
+    memcpy(j->dst, j->src, j->bytes);
+    return NULL;
+}
+
+/* pageable -> pinned, split over `threads` copier threads (joined before return; a host with its own thread pool would
+ * keep them alive and run this for chunk k+1 while it submits chunk k - here the overlap is with the GPU and PCIe only) */
+static void gather(uint8_t *dst, const uint8_t *src, size_t bytes, int threads)
+{
+    pthread_t th[MAXT];
+    copy_job jobs[MAXT];
+    if (threads > MAXT) threads = MAXT;
+    for (int t = 0; t < threads; t++) {
+        const size_t a = bytes * (size_t)t / threads, b = bytes * (size_t)(t + 1) / threads;
+        jobs[t].dst = dst + a; jobs[t].src = src + a; jobs[t].bytes = b - a;
+        pthread_create(&th[t], NULL, copier, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+}
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 120, h = argc > 2 ? atoi(argv[2]) : 1080, w = argc > 3 ? atoi(argv[3]) : 1920;
+    const int iv = argc > 4 ? atoi(argv[4]) : 10, chunk = argc > 5 ? atoi(argv[5]) : 24, threads = argc > 6 ? atoi(argv[6]) : 6;
+    if (n < 1 || h < 16 || w < 16 || iv < 1 || chunk < 1 || threads < 1) { fprintf(stderr, "bad arguments\n"); return 2; }
+    if (vqa_abi_version() != VQA_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 2; }
+    const size_t fb = (size_t)h * w * 3;
+    vqa_ctx *ctx[LANES] = {NULL, NULL};
+    for (int l = 0; l < LANES; l++) { CHECK(vqa_create(0, &ctx[l])); g_err_ctx = ctx[l]; }
+
+    /* the clip, as a caller that decoded two files holds it: malloc'ed.  Frame t shows pattern (t / iv) % 2, so selected
+     * frames alternate between two pictures; encoded = reference + 1 */
+    uint8_t *ref = (uint8_t *)malloc(fb * n), *enc = (uint8_t *)malloc(fb * n);
+    if (!ref || !enc) { fprintf(stderr, "out of host memory\n"); return 2; }
+    for (int t = 0; t < n; t++) {
+        unsigned s = 12345u + 977u * (unsigned)((t / iv) % 2);
+        uint8_t *r = ref + fb * t;
+        for (size_t i = 0; i < fb; i++) {
+            s = s * 1664525u + 1013904223u;
+            const unsigned v = ((i / 3 % w) * 3 + (i / (3 * (size_t)w) % h) * 2 + (s >> 27) + 40u * ((t / iv) % 2)) & 0xff;
+            r[i] = (uint8_t)(v > 254 ? 254 : v);
+        }
+        for (size_t i = 0; i < fb; i++) enc[fb * t + i] = (uint8_t)(r[i] + 1);
+    }
+    int pinned = -1;
+    CHECK(vqa_host_is_pinned(ctx[0], ref, &pinned));
+    if (pinned != 0) { fprintf(stderr, "malloc'ed memory reported as pinned\n"); return 1; }
+
+    /* the pinned ring (slot = halo frame + chunk of encoded frames, then the chunk of reference frames) and the lanes'
+     * device buffers of the same shape */
+    uint8_t *ring[SLOTS], *dev[LANES];
+    const size_t enc_bytes = fb * (size_t)(chunk + 1), slot_bytes = enc_bytes + fb * (size_t)chunk;
+    for (int s = 0; s < SLOTS; s++) CHECK(vqa_alloc_pinned(ctx[0], slot_bytes, (void **)&ring[s]));
+    for (int l = 0; l < LANES; l++) CHECK(vqa_alloc_device(ctx[l], slot_bytes, (void **)&dev[l]));
+    CHECK(vqa_host_is_pinned(ctx[0], ring[0], &pinned));
+    if (pinned != 1) { fprintf(stderr, "the ring is not page-locked\n"); return 1; }
+
+    vqa_params p;
+    vqa_default_params(&p);
+    p.resize_w = 64; p.resize_h = 64;                       /* the reference's config.json */
+    vqa_plane_desc planes[3];
+    for (int c = 0; c < 3; c++) {
+        planes[c].width = w; planes[c].height = h; planes[c].offset = c; planes[c].row_stride = (int64_t)w * 3;
+        planes[c].pixel_step = 3; planes[c].pad_ = 0;
+    }
+    const int nsel = n / iv;                                /* selected frames: 0-based index t with (t + 1) % iv == 0 */
+    const int nsamp = nsel > 1 ? nsel - 1 : 0;              /* the first selected frame only primes (complexity_metrics.py:271) */
+    vqa_frame_metrics *fm = (vqa_frame_metrics *)calloc(nsamp ? nsamp : 1, sizeof *fm);
+    vqa_plane_metrics *pm = (vqa_plane_metrics *)calloc((size_t)n * 3, sizeof *pm);
+    const int nchunks = (n + chunk - 1) / chunk;
+    struct { int a, b, j0, j1, slot; } pend[LANES];
+    int npend = 0, head = 0, free_slot[SLOTS], nfree = SLOTS;
+    for (int s = 0; s < SLOTS; s++) free_slot[s] = s;
+
+    /* two passes over the clip: the first grows the contexts' scratch and builds their tables (what a long-running host
+     * has done long ago), the second is timed */
+    double t0 = 0;
+    for (int pass = 0; pass < 2; pass++) {
+    head = 0; /* (every chunk of the previous pass has been waited for: npend == 0, all slots free) */
+    t0 = now_s();
+    for (int k = 0; k <= nchunks; k++) {
+        /* 1. stage chunk k into a free ring slot (the previous submit is already running on the other lane) */
+        int slot = -1, a = 0, b = 0, j0 = 0, j1 = 0;
+        if (k < nchunks) {
+            a = k * chunk; b = a + chunk < n ? a + chunk : n;
+            /* samples whose frame lies in [a, b): sample j measures selected frame (j + 2) * iv - 1 against (j + 1) * iv - 1 */
+            j0 = (a + 1 + iv - 1) / iv - 2; if (j0 < 0) j0 = 0;
+            j1 = b / iv - 1; if (j1 > nsamp) j1 = nsamp; if (j1 < j0) j1 = j0;
+            slot = free_slot[--nfree];
+            uint8_t *s = ring[slot];
+            if (j1 > j0 && (j0 + 1) * iv - 1 < a) gather(s, enc + fb * (size_t)((j0 + 1) * iv - 1), fb, 1); /* halo: the previous selected frame */
+            gather(s + fb, enc + fb * (size_t)a, fb * (size_t)(b - a), threads);
+            gather(s + enc_bytes, ref + fb * (size_t)a, fb * (size_t)(b - a), threads);
+        }
+        /* 2. the lane chunk k will use must be idle: wait for the chunk that ran on it two steps ago */
+        if (npend == LANES || (k == nchunks && npend > 0)) {
+            do {
+                const int l = head % LANES;
+                const int qa = pend[l].a, qb = pend[l].b;
+                g_err_ctx = ctx[l];
+                CHECK(vqa_quality_wait(ctx[l], pm + (size_t)qa * 3, (qb - qa) * 3));
+                if (pend[l].j1 > pend[l].j0) CHECK(vqa_complexity_wait(ctx[l], fm + pend[l].j0, pend[l].j1 - pend[l].j0));
+                free_slot[nfree++] = pend[l].slot;           /* every copy out of the slot has completed */
+                head++; npend--;
+            } while (k == nchunks && npend > 0);
+        }
+        if (k == nchunks) break;
+        /* 3. upload once, submit both halves on this lane's stream */
+        const int l = k % LANES;
+        g_err_ctx = ctx[l];
+        uint8_t *d = dev[l], *s = ring[slot];
+        const int halo = j1 > j0 && (j0 + 1) * iv - 1 < a;
+        CHECK(vqa_copy_h2d(ctx[l], d + (halo ? 0 : fb), s + (halo ? 0 : fb), fb * (size_t)(b - a + (halo ? 1 : 0))));
+        CHECK(vqa_copy_h2d(ctx[l], d + enc_bytes, s + enc_bytes, fb * (size_t)(b - a)));
+        CHECK(vqa_quality_submit(ctx[l], d + enc_bytes, d + fb, VQA_MEM_DEVICE, b - a, (int64_t)fb, (int64_t)fb, planes, 3, VQA_SSIM_GAUSS));
+        if (j1 > j0) {
+            const int first = (j0 + 2) * iv - 1 - a, prev = (j0 + 1) * iv - 1 - a; /* positions inside the chunk (prev < 0: the halo slot) */
+            CHECK(vqa_complexity_submit(ctx[l], d + fb * (size_t)(1 + first), d + fb * (size_t)(1 + (prev < 0 ? -1 : prev)), VQA_MEM_DEVICE,
+                                        j1 - j0, h, w, (int64_t)fb * iv, (int64_t)w * 3, VQA_M_ALL, &p));
+        }
+        pend[l].a = a; pend[l].b = b; pend[l].j0 = j0; pend[l].j1 = j1; pend[l].slot = slot;
+        npend++;
+    }
+    }
+    const double dt = now_s() - t0;
+
+    int bad = 0;
+    for (int t = 0; t < n; t++)
+        for (int c = 0; c < 3; c++) bad += pm[(size_t)t * 3 + c].sse != (unsigned long long)h * w; /* ref vs ref + 1 */
+    for (int j = 0; j < nsamp; j++) {
+        unsigned long long mass = 0;
+        for (int bin = 0; bin < 256; bin++) mass += fm[j].hist_gray[bin];
+        bad += mass != 64ull * 64ull;                        /* every pixel of the 64x64 thumbnail in exactly one bin */
+        bad += fm[j].has_prev != 1u;
+        if (j >= 2) {                                        /* period 2 in the selected frames: identical records */
+            bad += memcmp(fm[j].hist_gray, fm[j - 2].hist_gray, sizeof fm[j].hist_gray) != 0;
+            bad += fm[j].edge_count != fm[j - 2].edge_count || fm[j].dct_energy != fm[j - 2].dct_energy;
+            bad += fm[j].sad_sum != fm[j - 2].sad_sum || fm[j].temporal_dct_l1 != fm[j - 2].temporal_dct_l1;
+        }
+    }
+    printf("vqa_stream: %d frames %dx%d (interval %d: %d samples) from pageable memory in %.1f ms = %.0f frames/s, %.1f GB/s over PCIe\n",
+           n, w, h, iv, nsamp, dt * 1e3, n / dt, 2.0 * (double)fb * n / dt / 1e9);
+    if (nsamp) printf("sample 0: edges %u  dct_energy %.6g  temporal %.6g  sad/blk %.1f  ssim(B) of frame 0 %.6f\n", fm[0].edge_count,
+                      fm[0].dct_energy, fm[0].temporal_dct_l1, fm[0].sad_blocks ? (double)fm[0].sad_sum / fm[0].sad_blocks : 0.0, pm[0].ssim);
+    for (int l = 0; l < LANES; l++) { g_err_ctx = ctx[l]; CHECK(vqa_trim(ctx[l])); CHECK(vqa_free_device(ctx[l], dev[l])); }
+    for (int s = 0; s < SLOTS; s++) CHECK(vqa_free_pinned(ctx[0], ring[s]));
+    for (int l = 0; l < LANES; l++) CHECK(vqa_destroy(ctx[l]));
+    free(fm); free(pm); free(ref); free(enc);
+    if (bad) { fprintf(stderr, "%d self-checks failed\n", bad); return 1; }
+    puts("vqa_stream ok");
+    return 0;
+}

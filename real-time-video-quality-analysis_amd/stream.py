@@ -33,7 +33,12 @@ from . import tails
 from .engine import DeviceBuffer, DeviceFrames, Engine
 from .pooling import shard_range
 
-CHUNK_BYTES_MAX = 1 << 30     # per chunk and stream on the device / in a ring slot (a chunk is at most batch_size frames)
+# A chunk is at most batch_size frames and at most this many bytes (all streams together) on the device.  Chunks that go through
+# the pinned ring are smaller: the first chunk's gather overlaps nothing, so short chunks start the pipeline sooner (measured on
+# 300 x 1080p pairs, frames/s at 64 / 128 / 256 / 512 / 1024 MiB - pageable: 4006 / 4137 / 4145 / 4075 / 3790, config.json's
+# interval 10: 3591 / 3748 / 3932 / 4041 / 3865; pinned, no gather: 3735 / 3970 / 4054 / 4064 / 4036 and 3756 / 3934 / 4056 / 4171 / 4194)
+CHUNK_BYTES_MAX = 1 << 30
+STAGED_CHUNK_BYTES_MAX = 384 << 20
 STAGE_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))  # copier threads of the pinned ring
 MAX_LANES = 2                 # engines a pass alternates its chunks between (1: everything on the default engine, in order)
 
@@ -285,7 +290,10 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
     fb = src.fb
     # ---- chunks: (a, b) dense source range (quality present) or (j0, j1) sample range (complexity only)
     per_frame = fb * (2 if want_q else 1)
-    cap = max(1, min(int(batch_size), CHUNK_BYTES_MAX // max(per_frame, 1) if src.kind != "device" else int(batch_size)))
+    host = src.kind != "device"
+    staged = host and (src.kind == "pageable" or (want_q and rsrc.kind == "pageable"))
+    limit = STAGED_CHUNK_BYTES_MAX if staged else CHUNK_BYTES_MAX
+    cap = max(1, min(int(batch_size), limit // max(per_frame, 1) if host else int(batch_size)))
     chunks = [(a, min(a + cap, n)) for a in range(0, n, cap)] if want_q else [(j, min(j + cap, hi)) for j in range(lo, hi, cap)]
     # ---- lanes
     farneback = want_c and (complexity.mask & N.M_MOTION) and complexity.motion_mode == N.MOTION_FARNEBACK
@@ -293,8 +301,6 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
         lanes = [first]  # (Farneback keeps GiB-sized scratch per context and fills the chip on its own: one context)
     else:
         lanes = list(get_engine_pair(first.device))
-    host = src.kind != "device"
-    staged = host and (src.kind == "pageable" or (want_q and rsrc.kind == "pageable"))
     st = _staging_of(first) if host else None
     params = first.make_params(resize=complexity.resize, dct_mode=complexity.dct_mode,
                                motion_mode=complexity.motion_mode) if want_c else None
@@ -388,18 +394,25 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
 
     sse, ssim = [], []
 
-    def collect(p, eng):
+    def wait(p, eng):
+        """block until the chunk is done on its lane; its records are kept, its ring slot is free again"""
         if p["has_q"]:
-            res = eng.quality_wait()
-            sse.append(res["sse"])
-            ssim.append(res["ssim"])
+            p["qres"] = eng.quality_wait()
         if p["has_c"]:
-            rec = eng.complexity_wait()
+            p["rec"] = eng.complexity_wait()
         if staged:
             free_slots.append(p["slot"])  # every copy out of the slot has completed
-        if p["has_q"] and on_quality is not None:
-            on_quality(p["q0"], sse[-1], ssim[-1])
+
+    def finish(p):
+        """the host work of a finished chunk: float tails and stats lines (runs AFTER the lane has its next chunk)"""
+        if p["has_q"]:
+            res = p.pop("qres")
+            sse.append(res["sse"])
+            ssim.append(res["ssim"])
+            if on_quality is not None:
+                on_quality(p["q0"], sse[-1], ssim[-1])
         if p["has_c"]:
+            rec = p.pop("rec")
             for kind in KINDS:
                 if complexity.mask & MASK[kind]:
                     series[kind].extend(tails.scalars(kind, rec, complexity.motion_mode))
@@ -414,15 +427,21 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
         start_fill(nxt)
         for k in range(len(chunks)):
             p, eng = nxt, lanes[k % len(lanes)]
+            done = None
             if len(pending) == len(lanes):
-                collect(*pending.pop(0))
+                done = pending.pop(0)[0]
+                wait(done, eng)          # (the oldest pending chunk ran on this very lane)
             if k + 1 < len(chunks):  # the copiers work on chunk k + 1 while chunk k is enqueued and runs
                 nxt = plan(k + 1)
                 start_fill(nxt)
             submit(p, eng)
             pending.append((p, eng))
+            if done is not None:         # the lane is busy again: now the finished chunk's host work
+                finish(done)
         while pending:
-            collect(*pending.pop(0))
+            p, eng = pending.pop(0)
+            wait(p, eng)
+            finish(p)
     except BaseException:
         _abandon(lanes)
         raise

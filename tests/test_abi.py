@@ -192,6 +192,31 @@ def test_multi_device_c_host_rehearsal_three_workers_on_one_gpu(tmp_path):
     assert r.returncode == 1 and "two contexts on device 0" in r.stderr, r.stdout + r.stderr
 
 
+def test_streaming_c_host_builds_and_stops_without_a_device(tmp_path):
+    """examples/vqa_stream.c - the one-pass pipeline (pinned ring, copier threads, two contexts, one upload for both halves)
+    against include/vqa.h alone: compiles with -Wall -Werror; without a GPU it stops at vqa_create (no CPU fallback)."""
+    import subprocess
+    from rtvqa_amd import _native as N
+    exe = _build_demo(tmp_path, "vqa_stream")
+    n = C.c_int(-1)
+    N.load().vqa_device_count(C.byref(n))
+    if n.value == 0:
+        r = subprocess.run([exe, "10", "64", "64", "2", "3", "2"], capture_output=True, text=True)
+        assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("60", "270", "480", "5", "7", "3"), ("33", "96", "128", "1", "4", "2"),
+                                  ("120", "1080", "1920", "10", "24", "6"), ("9", "64", "64", "10", "100", "1")])
+def test_streaming_c_host_runs_on_the_gpu(tmp_path, args):
+    """The plain-C streaming host on the GPU: pageable clip -> ring -> ONE upload per chunk -> quality of every frame and
+    the complexity suite of every interval-th frame (halo frames across chunk seams, chunks that hold no sample, a clip too
+    short to hold one); its self-checks (SSE of ref vs ref + 1, histogram mass, period-2 records) must hold."""
+    import subprocess
+    r = subprocess.run([_build_demo(tmp_path, "vqa_stream"), *args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "vqa_stream ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_plain_c_host_runs_on_the_gpu(tmp_path):
     import subprocess
