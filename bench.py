@@ -199,7 +199,9 @@ def cpu_baseline(h, w, full, sample, motion="sad", verify_items=()):
             results.extend(ex.map(_cpu_item, items[i:i + 100]))
         dt = time.perf_counter() - t0
         expect = dict(ex.map(_expect_item, verify_items))  # the checker for "verified": same pool, not timed
-    line = dict(value=round(sample / dt, 3), unit="frames/s", cores=cores, workers=workers, workers_override=override,
+    # `cores` = the worker processes that actually ran (the contract's "threads you actually used"); visible_cores = what
+    # os.sched_getaffinity shows the process, which is what the reference's cpu_count() // 2 rule starts from
+    line = dict(value=round(sample / dt, 3), unit="frames/s", cores=workers, visible_cores=cores, workers=workers, workers_override=override,
                 cgroup_cpu_limit=cgroup_cpu_limit(), kind="port", seconds=round(dt, 2),
                 sample="%d frame pairs of the same workload, oracle/ C port under ProcessPoolExecutor(max_workers="
                        "cores//2 = %d of the %d cores visible to the process), chunksize 1, batch_size 100"
@@ -554,7 +556,9 @@ def cpu_baseline_c1(ref, dist):
     t0 = time.perf_counter()
     tup, q = c1_oracle(ref, dist, workers)
     dt = time.perf_counter() - t0
-    line = dict(value=round(sample / dt, 3), unit="frames/s", cores=cores, workers=workers, workers_override=override,
+    # `cores` = the worker processes that actually ran (the contract's "threads you actually used"); visible_cores = what
+    # os.sched_getaffinity shows the process, which is what the reference's cpu_count() // 2 rule starts from
+    line = dict(value=round(sample / dt, 3), unit="frames/s", cores=workers, visible_cores=cores, workers=workers, workers_override=override,
                 cgroup_cpu_limit=cgroup_cpu_limit(), kind="port", seconds=round(dt, 2),
                 sample="%d frames of the same clip through oracle/pipeline.py: PSNR/SSIM of every frame "
                        "pair under ProcessPoolExecutor(max_workers=cores//2 = %d of %d visible cores), then "

@@ -422,6 +422,7 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
                 series["temporal"].extend(t[1:] if p["j0"] == 0 else t)
 
     pending = []
+    nxt = None
     try:
         nxt = plan(0)
         start_fill(nxt)
@@ -443,6 +444,11 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
             wait(p, eng)
             finish(p)
     except BaseException:
+        for f in (nxt or {}).get("fill", ()):  # a copier may still be writing into the ring: the next pass must not meet it
+            try:
+                f.result()
+            except Exception:
+                pass
         _abandon(lanes)
         raise
     q = (np.concatenate(sse), np.concatenate(ssim)) if want_q else None

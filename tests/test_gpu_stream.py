@@ -202,3 +202,36 @@ def test_torch_tensors_are_accepted_in_place():
                                              csv_file=os.devnull)
     m2 = vp.process_video_and_extract_metrics(ref, dist, {"resize_width": 64, "resize_height": 64, "frame_interval": 2}, csv_file=os.devnull)
     assert m["PSNR"] == m2["PSNR"] and m["SSIM"] == m2["SSIM"] and m["DCT Complexity"] == m2["DCT Complexity"]
+
+
+def test_a_failure_inside_a_pass_leaves_the_engines_usable(tmp_path):
+    """The reference's convention for a failed step is log, re-raise, nothing left running (video_processing.py:295-297).
+    A callback that raises in the middle of a pass (here: the stats writer of chunk 1): the exception surfaces, nothing is
+    pending on either lane afterwards, and the next pass on the same engines returns the right bits."""
+    from rtvqa_amd import complexity_metrics as cm
+    from rtvqa_amd import stream, synth
+    from rtvqa_amd import video_processing as vp
+    ref = _clip(30, 96, 128, seed=71)
+    dist = synth.distort(ref)
+    want_q, want_s = stream.run(dist, ref, stream.Quality(vp.bgr_planes(96, 128)), stream.Complexity((64, 64), 2), batch_size=1000,
+                                engine=cm.get_engine())
+    calls = []
+
+    def boom(first, sse, ssim):
+        calls.append(first)
+        if len(calls) == 2:
+            raise OSError("disk full")
+
+    with pytest.raises(OSError):
+        stream.run(dist, ref, stream.Quality(vp.bgr_planes(96, 128)), stream.Complexity((64, 64), 2), batch_size=4, on_quality=boom)
+    for e in stream.get_engine_pair():
+        assert not getattr(e, "_pending_c", None) and not getattr(e, "_pending_q", None)
+    got_q, got_s = stream.run(dist, ref, stream.Quality(vp.bgr_planes(96, 128)), stream.Complexity((64, 64), 2), batch_size=4)
+    assert np.array_equal(got_q[0], want_q[0]) and np.array_equal(got_q[1], want_q[1])
+    _same_series(got_s, want_s)
+    # a submit that the C side refuses (a plane smaller than the SSIM window) surfaces as VqaError, same guarantees
+    from rtvqa_amd import _native as N
+    tiny = np.zeros((5, 8, 8, 3), np.uint8)
+    with pytest.raises(N.VqaError):
+        vp.frame_quality(tiny, tiny, batch_size=2)
+    _same_series(stream.run(dist, complexity=stream.Complexity((64, 64), 2), batch_size=4)[1], want_s)
