@@ -232,6 +232,50 @@ def selected_indices(num_frames, frame_interval):
     return np.arange(frame_interval - 1, num_frames, frame_interval)
 
 
+def plan_chunks(n, want_q, interval, lo, hi, cap):
+    """The chunks of a pass, as pure arithmetic (no engine, no frames): -> list of dicts.
+
+    n frames; quality wanted or not; complexity samples lo..hi-1 of the series at `interval` (None: no complexity), where
+    sample j measures selected frame idx[1 + j] against idx[j], idx = selected_indices(n, interval); `cap` frames per chunk.
+    A chunk's frames sit in a buffer of cap + 1 frame slots, slot 0 being the halo (the frame before the chunk's first
+    sample when it lies before the chunk).  Per chunk:
+      q0, qn        quality: source frames q0 .. q0 + qn - 1, in slots 1 .. qn           (quality passes)
+      j0, j1        complexity samples j0 .. j1 - 1; their frames sit in slots 1 + first + i * step, prev0 in slot
+                    1 + prev_slot (prev_slot = -1: the halo slot)
+      copies        (slot, first source frame, count, source step) of the distorted stream; rcopies: of the reference
+    With quality the chunk is the dense source range [q0, q0 + qn) and the samples are every interval-th frame of it;
+    without, the chunk holds exactly the samples' frames (compact), so only selected frames ever move."""
+    plans = []
+    if want_q:
+        idx = selected_indices(n, interval) if interval else None
+        for k, a in enumerate(range(0, n, cap)):
+            b = min(a + cap, n)
+            p = dict(k=k, q0=a, qn=b - a, j0=0, j1=0, copies=[], rcopies=[(0, a, b - a, 1)])
+            if interval and hi > lo:
+                # samples whose frame lies in [a, b): sample j measures selected frame idx[1 + j]
+                j0 = max(lo, int(np.searchsorted(idx, a)) - 1, 0)
+                j1 = max(j0, min(hi, int(np.searchsorted(idx, b)) - 1))
+                p.update(j0=j0, j1=j1)
+                if j1 > j0:
+                    prev = int(idx[j0])
+                    p.update(first=int(idx[1 + j0]) - a, step=interval, prev_slot=(prev - a) if prev >= a else -1)
+                    if prev < a:
+                        p["copies"].append((0, prev, 1, 1))
+            p["copies"].append((1, a, b - a, 1))
+            plans.append(p)
+        return plans
+    idx = selected_indices(n, interval)
+    for k, j0 in enumerate(range(lo, hi, cap)):
+        j1 = min(j0 + cap, hi)
+        p = dict(k=k, j0=j0, j1=j1, first=0, step=1, prev_slot=-1, rcopies=[])
+        if interval == 1:  # the frame before the first sample and the samples are one contiguous range
+            p["copies"] = [(0, int(idx[j0]), j1 - j0 + 1, 1)]
+        else:
+            p["copies"] = [(0, int(idx[j0]), 1, 1), (1, int(idx[1 + j0]), j1 - j0, interval)]
+        plans.append(p)
+    return plans
+
+
 class Complexity:
     """What the complexity half of a pass measures (arguments of calculate_average_scene_complexity)."""
 
@@ -294,10 +338,10 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
     staged = host and (src.kind == "pageable" or (want_q and rsrc.kind == "pageable"))
     limit = STAGED_CHUNK_BYTES_MAX if staged else CHUNK_BYTES_MAX
     cap = max(1, min(int(batch_size), limit // max(per_frame, 1) if host else int(batch_size)))
-    chunks = [(a, min(a + cap, n)) for a in range(0, n, cap)] if want_q else [(j, min(j + cap, hi)) for j in range(lo, hi, cap)]
+    nchunks = -(-n // cap) if want_q else -(-(hi - lo) // cap)
     # ---- lanes
     farneback = want_c and (complexity.mask & N.M_MOTION) and complexity.motion_mode == N.MOTION_FARNEBACK
-    if engine is not None or len(chunks) <= 1 or farneback or MAX_LANES < 2:
+    if engine is not None or nchunks <= 1 or farneback or MAX_LANES < 2:
         lanes = [first]  # (Farneback keeps GiB-sized scratch per context and fills the chip on its own: one context)
     else:
         lanes = list(get_engine_pair(first.device))
@@ -312,36 +356,13 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
     ring = st.ring(len(lanes) + 1, (cap + 1) * fb + (cap * fb if want_q else 0)) if staged else None
     free_slots = list(range(len(ring))) if staged else None
 
+    plans = plan_chunks(n, want_q, complexity.interval if want_c else None, lo if want_c else 0, hi if want_c else 0, cap)
+
     def plan(k):
-        """the chunk's host copies and where its samples sit: -> dict"""
-        a, b = chunks[k]
-        p = dict(k=k, copies=[], rcopies=[])
-        if want_q:
-            p.update(q0=a, qn=b - a)
-            if want_c:
-                # samples whose frame lies in [a, b): sample j measures selected frame idx[1 + j]
-                iv = complexity.interval
-                j0 = max(lo, int(np.searchsorted(idx, a)) - 1, 0)
-                j1 = max(j0, min(hi, int(np.searchsorted(idx, b)) - 1))
-                p.update(j0=j0, j1=j1)
-                if j1 > j0:
-                    prev = int(idx[j0])
-                    p.update(first=int(idx[1 + j0]) - a, step=iv, prev_slot=(prev - a) if prev >= a else -1)
-                    if host and prev < a:
-                        p["copies"].append(_Copy(0, src.view(prev, 1)))
-            if host:
-                p["copies"].append(_Copy(1, src.view(a, b - a)))
-                p["rcopies"].append(_Copy(0, rsrc.view(a, b - a)))
-        else:
-            j0, j1 = a, b
-            iv = complexity.interval
-            p.update(j0=j0, j1=j1, first=0, step=1, prev_slot=-1)
-            if host:
-                if iv == 1:  # the frame before the first sample and the samples are one contiguous range
-                    p["copies"].append(_Copy(0, src.view(int(idx[j0]), j1 - j0 + 1)))
-                else:
-                    p["copies"].append(_Copy(0, src.view(int(idx[j0]), 1)))
-                    p["copies"].append(_Copy(1, src.view(int(idx[1 + j0]), j1 - j0, iv)))
+        """chunk k's plan with its host copies as views of the sources"""
+        p = dict(plans[k])
+        p["copies"] = [_Copy(slot, src.view(start, count, step)) for slot, start, count, step in p["copies"]] if host else []
+        p["rcopies"] = [_Copy(slot, rsrc.view(start, count, step)) for slot, start, count, step in p["rcopies"]] if host else []
         return p
 
     def start_fill(p):
@@ -426,13 +447,13 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
     try:
         nxt = plan(0)
         start_fill(nxt)
-        for k in range(len(chunks)):
+        for k in range(nchunks):
             p, eng = nxt, lanes[k % len(lanes)]
             done = None
             if len(pending) == len(lanes):
                 done = pending.pop(0)[0]
                 wait(done, eng)          # (the oldest pending chunk ran on this very lane)
-            if k + 1 < len(chunks):  # the copiers work on chunk k + 1 while chunk k is enqueued and runs
+            if k + 1 < nchunks:  # the copiers work on chunk k + 1 while chunk k is enqueued and runs
                 nxt = plan(k + 1)
                 start_fill(nxt)
             submit(p, eng)

@@ -1,0 +1,62 @@
+"""stream.plan_chunks - the arithmetic of a pass (which frames a chunk uploads, where its samples and their previous frames
+sit) - against a brute-force model of the reference's selection (complexity_metrics.py:103-104: 1-based count % interval ==
+0; :268-290: sample j measures selected frame S_{j+1} against S_j; :533-537).  No engine, no GPU: every (n, interval, cap,
+shard) combination is simulated on a buffer of frame numbers."""
+import itertools
+
+import numpy as np
+import pytest
+
+from rtvqa_amd import stream
+from rtvqa_amd.pooling import shard_range
+
+
+def _simulate(n, want_q, interval, lo, hi, cap):
+    """run the plans on buffers of frame ids; -> (quality frames in order, [(frame, prev)] per sample in order, frames uploaded)"""
+    qframes, samples, uploaded = [], [], 0
+    for p in stream.plan_chunks(n, want_q, interval, lo, hi, cap):
+        buf = np.full(cap + 1, -1)
+        for slot, start, count, step in p["copies"]:
+            assert 0 <= slot and slot + count <= cap + 1, (p, "copy leaves the buffer")
+            src = np.arange(start, start + (count - 1) * step + 1, step)
+            assert src[-1] < n
+            buf[slot:slot + count] = src
+            uploaded += count
+        if want_q:
+            assert p["rcopies"] == [(0, p["q0"], p["qn"], 1)]
+            got = buf[1:1 + p["qn"]]
+            assert (got == np.arange(p["q0"], p["q0"] + p["qn"])).all()
+            qframes.extend(got.tolist())
+        for i in range(p["j1"] - p["j0"]):
+            f = buf[1 + p["first"] + i * p["step"]]
+            prev = buf[1 + p["prev_slot"]] if i == 0 else buf[1 + p["first"] + (i - 1) * p["step"]]
+            assert f >= 0 and prev >= 0, (p, "reads a slot nobody uploaded")
+            samples.append((int(f), int(prev)))
+        if p["j1"] > p["j0"]:
+            assert p["j0"] == lo + len(samples) - (p["j1"] - p["j0"])    # samples arrive in series order, none skipped
+    return qframes, samples, uploaded
+
+
+@pytest.mark.parametrize("want_q", [False, True])
+def test_every_chunking_measures_exactly_the_reference_samples(want_q):
+    for n, interval, cap in itertools.product((0, 1, 2, 5, 9, 10, 11, 29, 30, 31, 64, 101), (1, 2, 3, 7, 10), (1, 2, 3, 8, 100)):
+        sel = [t for t in range(n) if (t + 1) % interval == 0]                 # :103-104
+        want = [(sel[j + 1], sel[j]) for j in range(len(sel) - 1)]               # :268-290, previous = the selected frame before
+        shards = [None] if want_q else [None, (0, 2), (1, 2), (2, 3), (7, 8)]
+        for shard in shards:
+            lo, hi = shard_range(len(want), *shard) if shard else (0, len(want))
+            q, s, up = _simulate(n, want_q, interval, lo, hi, cap)
+            assert s == want[lo:hi], (n, interval, cap, shard)
+            if want_q:
+                assert q == list(range(n))
+                # one upload per frame, plus at most one halo frame per chunk
+                assert n <= up <= n + -(-n // cap)
+            elif hi > lo:
+                # only selected frames ever move: the samples' frames and one previous frame per chunk
+                assert up == (hi - lo) + -(-(hi - lo) // cap)
+
+
+def test_quality_only_passes_have_no_samples():
+    plans = stream.plan_chunks(25, True, None, 0, 0, 10)
+    assert [(p["q0"], p["qn"]) for p in plans] == [(0, 10), (10, 10), (20, 5)]
+    assert all(p["j0"] == p["j1"] for p in plans)
