@@ -153,6 +153,8 @@ class _Source:
             self.kind, self.n = "device", frames.n
             self.fb = frames.h * frames.w * frames.channels
             return
+        if frames.dtype != np.uint8:  # a silent cast (or, from pinned memory, a reinterpretation) would measure garbage
+            raise ValueError("frames must be uint8 (got %s): decoded 8-bit frames, as cv2.VideoCapture.read yields" % frames.dtype)
         self.n = frames.shape[0]
         self.fb = int(np.prod(frames.shape[1:], dtype=np.int64)) if frames.ndim > 1 else 1
         compact = self.n == 0 or (frames[0].flags.c_contiguous and (self.n == 1 or frames.strides[0] >= self.fb))
