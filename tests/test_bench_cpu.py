@@ -164,3 +164,22 @@ def test_verified_checker_accepts_the_oracle_and_rejects_a_wrong_record():
     q["ssim"][2] *= 1.0 + 3e-4
     bad = check.compare(exp, c, q, "gauss")
     assert len(bad) == 3 and any("hist_bgr" in b for b in bad) and any("edge" in b for b in bad) and any("ssim_gauss[2]" in b for b in bad)
+
+
+def test_dist_always_brings_up_a_group_of_one_without_a_launcher():
+    """--dist-always: the N > 1 code path (process group, MAX / SUM all-reduces, all_gather_object, barrier, teardown) with
+    the one rank there is, no launcher and no MASTER_* in the environment (bench.py supplies a rendezvous of one).  Here
+    under gloo with the engine stubbed; tests/test_gpu_rccl_one_rank.py runs the same path over real RCCL on the GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--stub-engine", "--backend", "gloo", "--dist-always", "--steps", "2", "--warmup", "1"],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["collective"] == "gloo scalar all-reduce" and line["config"]["backend"] == "gloo"
+    assert line["n_gpus"] == 1 and line["config"]["devices"] == [0]
+
+
+def test_c1_is_a_workload_and_refuses_the_stub():
+    assert bench.WORKLOADS["c1"]["batch"] == 300 and bench.C1_CONFIG["frame_interval"] == 10 and bench.C1_CONFIG["resize_width"] == 64
+    r = _run([sys.executable, "bench.py", "--workload", "c1", "--stub-engine", "--backend", "gloo"])
+    assert r.returncode != 0 and "c1 has no stub" in (r.stderr + r.stdout)
