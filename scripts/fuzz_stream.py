@@ -17,6 +17,8 @@ for case in range(n_cases):
     r = np.random.default_rng(seed0 + case)
     n, h, w = int(r.integers(1, 40)), int(r.integers(11, 120)), int(r.integers(11, 160))
     iv, batch = int(r.integers(1, 7)), int(r.integers(1, 12))
+    if case % 25 == 24:  # a long clip of small frames: dozens of chunks, both lanes and every ring slot many times over
+        n, h, w, batch = int(r.integers(200, 900)), int(r.integers(11, 64)), int(r.integers(11, 64)), int(r.integers(3, 40))
     rw, rh = (int(r.integers(8, 80)), int(r.integers(8, 80))) if case % 2 else (w, h)
     ref = synth.s_natural(n, h, w, seed=case) if case % 3 else r.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     dist = synth.distort(ref)
