@@ -335,6 +335,8 @@ def pool_series(s, video_path, frame_interval=10, smoothing_factor=0.8, num_work
         with np.errstate(invalid="ignore"), _quiet_empty_mean():
             return np.mean(smooth_data(x, smoothing_factor))
 
+    # the pass keeps every series as one float64 array too (the values the lists hold, without 256 NumPy scalars per list)
+    s = dict(s, **s.get("_float64", {}))
     temporal = smooth_data(s["temporal"], smoothing_factor)
     temporal_dct_complexity = np.mean(temporal) if len(temporal) > 0 else 0.0
     frame_timestamps = extract_frame_timestamps(video_path, frame_interval, fps)

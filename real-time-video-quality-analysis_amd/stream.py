@@ -416,6 +416,7 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
             p["has_c"] = True
 
     sse, ssim = [], []
+    arrays = {k: [] for k in KINDS + ("temporal",)}  # the same series as float64 arrays, for the pooling (no list round trip)
 
     def wait(p, eng):
         """block until the chunk is done on its lane; its records are kept, its ring slot is free again"""
@@ -438,11 +439,14 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
             rec = p.pop("rec")
             for kind in KINDS:
                 if complexity.mask & MASK[kind]:
-                    series[kind].extend(tails.scalars(kind, rec, complexity.motion_mode))
+                    v = tails.values(kind, rec, complexity.motion_mode)
+                    series[kind].extend(tails.as_list(kind, v))
+                    arrays[kind].append(v)
             if complexity.mask & N.M_TEMPORAL_DCT:
-                t = tails.scalars("temporal", rec)
                 # the reference's first pair only primes prev_gray_frame (:533-537)
-                series["temporal"].extend(t[1:] if p["j0"] == 0 else t)
+                v = tails.values("temporal", rec)[1 if p["j0"] == 0 else 0:]
+                series["temporal"].extend(tails.as_list("temporal", v))
+                arrays["temporal"].append(v)
 
     pending = []
     nxt = None
@@ -475,6 +479,8 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
         _abandon(lanes)
         raise
     q = (np.concatenate(sse), np.concatenate(ssim)) if want_q else None
+    if want_c:
+        series["_float64"] = {k: (np.concatenate(v).astype(np.float64) if v else np.zeros(0)) for k, v in arrays.items()}
     return q, series
 
 

@@ -115,21 +115,36 @@ def motion_magnitude_batch(rec, motion_mode):
     return out
 
 
+def values(kind, rec, motion_mode=N.MOTION_SAD):
+    """The series of `kind` for a batch of records as ONE NumPy array (float32 / int64 / uint32, the dtype scalar() returns)."""
+    if kind == "dct":
+        return rec["dct_energy"].astype(np.float32)
+    if kind == "temporal":
+        return rec["temporal_dct_l1"].astype(np.float32)
+    if kind == "hist":
+        return gray_entropy_batch(rec["hist_gray"])
+    if kind == "color":
+        return color_entropy_batch(rec["hist_bgr"])
+    if kind == "edge":
+        return rec["edge_count"].astype(np.int64)
+    if kind == "motion":
+        return motion_magnitude_batch(rec, motion_mode)
+    if kind == "orb":
+        return np.ascontiguousarray(rec["orb_keypoints"])
+    raise KeyError(kind)
+
+
+def as_list(kind, v):
+    """values() as a list whose items have the types scalar() returns (NumPy scalars; Python ints for the ORB count; a
+    Python float NaN where a colour channel is empty, :464-465)"""
+    if kind == "orb":
+        return v.tolist()
+    out = list(v)
+    if kind == "color" and np.isnan(v).any():
+        out = [float("nan") if x != x else x for x in out]
+    return out
+
+
 def scalars(kind, rec, motion_mode=N.MOTION_SAD):
     """The series of `kind` for a batch of records, as a list whose items have the types scalar() returns."""
-    if kind == "dct":
-        return list(rec["dct_energy"].astype(np.float32))
-    if kind == "temporal":
-        return list(rec["temporal_dct_l1"].astype(np.float32))
-    if kind == "hist":
-        return list(gray_entropy_batch(rec["hist_gray"]))
-    if kind == "color":
-        out = list(color_entropy_batch(rec["hist_bgr"]))
-        return [float("nan") if v != v else v for v in out] if any(v != v for v in out) else out
-    if kind == "edge":
-        return list(rec["edge_count"].astype(np.int64))
-    if kind == "motion":
-        return list(motion_magnitude_batch(rec, motion_mode))
-    if kind == "orb":
-        return rec["orb_keypoints"].tolist()
-    raise KeyError(kind)
+    return as_list(kind, values(kind, rec, motion_mode))
