@@ -62,14 +62,19 @@ def get_engine(device=None):
         return _engines[device]
 
 
-def get_engine_pair(device=None):
-    """Two engines (= two HIP streams with their own scratch) on one device: while chunk k's kernels run on one,
-    chunk k+1 crosses PCIe on the other."""
+def get_engine_lanes(device=None, count=2):
+    """`count` engines (= HIP streams with their own scratch) on one device: while chunk k's kernels run on one,
+    chunk k+1 crosses PCIe on the next.  The first is the device's default engine."""
     first = get_engine(device)
     with _lock:
-        if first.device not in _second:
-            _second[first.device] = Engine(first.device)
-        return first, _second[first.device]
+        more = _second.setdefault(first.device, [])
+        while len(more) < count - 1:
+            more.append(Engine(first.device))
+        return (first,) + tuple(more[:count - 1])
+
+
+def get_engine_pair(device=None):
+    return get_engine_lanes(device, 2)
 
 
 class _Staging:
@@ -136,9 +141,8 @@ def release_buffers(device=None):
         for d in devs:
             if d in _staging:
                 _staging.pop(d).release()
-            for table in (_engines, _second):
-                if d in table:
-                    table[d].trim()
+            for e in ([_engines[d]] if d in _engines else []) + list(_second.get(d, ())):
+                e.trim()
 
 
 # ---------------------------------------------------------------------------
@@ -346,7 +350,7 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
     if engine is not None or nchunks <= 1 or farneback or MAX_LANES < 2:
         lanes = [first]  # (Farneback keeps GiB-sized scratch per context and fills the chip on its own: one context)
     else:
-        lanes = list(get_engine_pair(first.device))
+        lanes = list(get_engine_lanes(first.device, min(MAX_LANES, nchunks)))
     st = _staging_of(first) if host else None
     params = first.make_params(resize=complexity.resize, dct_mode=complexity.dct_mode,
                                motion_mode=complexity.motion_mode) if want_c else None

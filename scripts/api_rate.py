@@ -32,6 +32,22 @@ for name, (r, d) in (("resident", (dev_r, dev_d)), ("host_pinned", (pin_r, pin_d
         best = min(best, time.perf_counter() - t0)
     print("%-14s %8.0f frames/s (%d frames, best of 3: %.1f ms; first call %.1f ms)  PSNR %.2f SSIM %.4f"
           % (name, n / best, n, best * 1e3, warm * 1e3, m["PSNR"], m["SSIM"]), flush=True)
+for lanes in (1, 2, 3, 4):
+    stream.MAX_LANES = lanes
+    cm.release_buffers()
+    out = []
+    for name, (r, d) in (("resident", (dev_r, dev_d)), ("host_pinned", (pin_r, pin_d)), ("host_pageable", (ref, dist))):
+        vp.process_video_and_extract_metrics(r, d, cfg, csv_file=csv)
+        best = 1e9
+        for _ in range(4):
+            t0 = time.perf_counter()
+            vp.process_video_and_extract_metrics(r, d, cfg, csv_file=csv)
+            best = min(best, time.perf_counter() - t0)
+        out.append("%s %6.0f" % (name, n / best))
+    print("lanes %d: %s frames/s" % (lanes, "  ".join(out)), flush=True)
+stream.MAX_LANES = 2
+if os.environ.get("API_SWEEPS", "1") == "0":
+    raise SystemExit(0)
 for mb in (64, 128, 160, 256, 512, 1024):
     stream.CHUNK_BYTES_MAX = stream.STAGED_CHUNK_BYTES_MAX = mb << 20
     cm.release_buffers()
