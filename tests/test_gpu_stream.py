@@ -170,10 +170,21 @@ def test_table_caches_stay_bounded_over_200_geometries():
 
 
 def test_release_buffers_then_the_api_still_works():
+    """release_buffers(): the pinned ring, the lane buffers and (vqa_trim) every engine's scratch go back - the device's free
+    memory returns to where it was before the passes (within 64 MiB) - and the next call re-grows what it needs."""
     from rtvqa_amd import complexity_metrics as cm
+    from rtvqa_amd import synth
+    from rtvqa_amd import video_processing as vp
     clip = _clip(12, 90, 120, seed=3)
     a = cm.complexity_series(clip, 64, 64, 1, batch_size=4)
     cm.release_buffers()
+    base = _free_bytes()
+    big = _clip(40, 540, 960, seed=4)                       # 62 MB per stream: lane buffers, ring and scratch well above the bar
+    vp.frame_quality(big, synth.distort(big), batch_size=16)
+    cm.complexity_series(big, 960, 540, 1, batch_size=16)
+    assert base - _free_bytes() > (64 << 20)
+    cm.release_buffers()
+    assert abs(_free_bytes() - base) <= (64 << 20)
     _same_series(cm.complexity_series(clip, 64, 64, 1, batch_size=4), a)
 
 
