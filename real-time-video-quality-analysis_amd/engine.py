@@ -172,6 +172,21 @@ class Engine:
     def sync(self):
         N.check(self.lib.vqa_sync(self.ctx), "vqa_sync", self.ctx)
 
+    def drain(self):
+        """Wait out whatever this engine still has pending (a quality and / or a complexity batch), discard the results and
+        synchronise its streams: after a failure in the caller's loop nothing reads the caller's buffers any more and the
+        engine is usable again.  Never raises."""
+        for pend, wait in (("_pending_q", self.quality_wait), ("_pending_c", self.complexity_wait)):
+            try:
+                if getattr(self, pend, None):
+                    wait()
+            except Exception:
+                setattr(self, pend, None)
+        try:
+            self.sync()
+        except Exception:
+            pass
+
     def trim(self):
         """vqa_trim: give back every scratch buffer, the result staging and every cached table of this (idle) engine.
         The next submit re-grows what it needs; results are unaffected."""

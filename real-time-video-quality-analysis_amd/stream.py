@@ -493,16 +493,7 @@ def _abandon(lanes):
     video_processing.py:295-297): wait out whatever the lanes still have pending, so that nothing reads the ring, the
     lane buffers or the caller's frames any more when the error surfaces, and the engines stay usable."""
     for eng in lanes:
-        for pend, wait in (("_pending_q", eng.quality_wait), ("_pending_c", eng.complexity_wait)):
-            try:
-                if getattr(eng, pend, None):
-                    wait()
-            except Exception:
-                setattr(eng, pend, None)
-        try:
-            eng.sync()
-        except Exception:
-            pass
+        eng.drain()
 
 
 def _device_of(frames):

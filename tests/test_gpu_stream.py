@@ -219,6 +219,7 @@ def test_a_failure_inside_a_pass_leaves_the_engines_usable(tmp_path):
     """The reference's convention for a failed step is log, re-raise, nothing left running (video_processing.py:295-297).
     A callback that raises in the middle of a pass (here: the stats writer of chunk 1): the exception surfaces, nothing is
     pending on either lane afterwards, and the next pass on the same engines returns the right bits."""
+    from rtvqa_amd import _native as N
     from rtvqa_amd import complexity_metrics as cm
     from rtvqa_amd import stream, synth
     from rtvqa_amd import video_processing as vp
@@ -236,12 +237,12 @@ def test_a_failure_inside_a_pass_leaves_the_engines_usable(tmp_path):
     with pytest.raises(OSError):
         stream.run(dist, ref, stream.Quality(vp.bgr_planes(96, 128)), stream.Complexity((64, 64), 2), batch_size=4, on_quality=boom)
     for e in stream.get_engine_pair():
-        assert not getattr(e, "_pending_c", None) and not getattr(e, "_pending_q", None)
+        buf = (N.VqaFrameMetrics * 1)()
+        assert e.lib.vqa_complexity_wait(e.ctx, buf, 1) == N.VQA_ERR_STATE   # nothing is pending on the C side either
     got_q, got_s = stream.run(dist, ref, stream.Quality(vp.bgr_planes(96, 128)), stream.Complexity((64, 64), 2), batch_size=4)
     assert np.array_equal(got_q[0], want_q[0]) and np.array_equal(got_q[1], want_q[1])
     _same_series(got_s, want_s)
     # a submit that the C side refuses (a plane smaller than the SSIM window) surfaces as VqaError, same guarantees
-    from rtvqa_amd import _native as N
     tiny = np.zeros((5, 8, 8, 3), np.uint8)
     with pytest.raises(N.VqaError):
         vp.frame_quality(tiny, tiny, batch_size=2)
