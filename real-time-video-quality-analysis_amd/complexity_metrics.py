@@ -250,49 +250,79 @@ def process_in_batches(frames, process_func, num_workers, batch_size=100, **kwar
             results.extend(call(item) for item in frames[i:i + batch_size])
         return results
     eng = get_engine()
-    for i in range(0, len(frames), batch_size):
-        batch = frames[i:i + batch_size]
-        if kind == "motion":
-            results.extend(_motion_batch(eng, batch))
+    resize = None if kind in ("orb", "motion") else (kw["resize_width"], kw["resize_height"])
+    params = eng.make_params(resize=resize, motion_mode=_motion_mode)
+    call = functools.partial(process_func, **kwargs)
+    chunks = [_chunk_job(kind, frames[i:i + batch_size], call) for i in range(0, len(frames), batch_size)]
+    # the ring's two slots are sized ONCE for the largest chunk (a slot is never re-allocated while its neighbour is in flight)
+    slot_bytes = max([sum(int(f.nbytes) for f in c["items"]) for c in chunks if c["items"]] or [0])
+
+    def start(k):
+        c = chunks[k]
+        return stream.stage_frames_start(eng, c["items"], slot=k & 1, slots=2, min_bytes=slot_bytes) if c["items"] else None
+
+    # Every chunk is ONE pinned buffer (gathered by the copier threads), ONE asynchronous upload, ONE launch - and while
+    # chunk k crosses PCIe and runs, the copiers gather chunk k + 1 into the ring's other slot.
+    nxt = start(0) if chunks else None
+    for k, c in enumerate(chunks):
+        cur = nxt
+        if cur is None:  # nothing to launch (frames of different sizes: per-item map; a chunk of None pairs: zeros)
+            results.extend(c["finish"](None))
+            nxt = start(k + 1) if k + 1 < len(chunks) else None
             continue
-        resize = None if kind == "orb" else (kw["resize_width"], kw["resize_height"])
+        arr, futs = cur
+        for f in futs:
+            f.result()
+        try:
+            if c["prev0"]:
+                eng.complexity_submit(arr[1:], arr[0], _MASK[kind], params)
+            else:
+                eng.complexity_submit(arr, None, _MASK[kind], params)
+            nxt = start(k + 1) if k + 1 < len(chunks) else None
+            rec = eng.complexity_wait()
+        except BaseException:
+            eng.drain()
+            for f in (nxt[1] if nxt else ()):  # (the copiers of the next chunk: the ring must be quiet when the error surfaces)
+                try:
+                    f.result()
+                except Exception:
+                    pass
+            raise
+        results.extend(c["finish"](rec))
+    return results
+
+
+def _chunk_job(kind, batch, call):
+    """One chunk of process_in_batches as a launch: the frames to stage (items; None = nothing to launch), whether slot 0 is
+    the frame before the first (prev0), and finish(records) -> the chunk's results in item order."""
+    if kind != "motion":
         # 2-D (gray) frames are expanded exactly as the per-frame callables do; a chunk whose frames differ in size
         # cannot be one launch and goes through the per-item map (what the reference's executor.map does anyway)
         items = [np.asarray(f) for f in batch]
         items = [np.repeat(f[..., None], 3, axis=2) if f.ndim == 2 else f for f in items]
         if len({f.shape for f in items}) > 1:
-            call = functools.partial(process_func, **kwargs)
-            results.extend(call(item) for item in batch)
-            continue
-        # the chunk in ONE pinned buffer (gathered by the copier threads), ONE asynchronous upload, ONE launch
-        rec = eng.complexity(stream.stage_frames(eng, items), mask=_MASK[kind], resize=resize)
-        results.extend(_scalars(kind, rec))
-    return results
-
-
-def _motion_batch(eng, pairs):
-    out = [None] * len(pairs)
+            return dict(items=None, prev0=False, finish=lambda rec: [call(item) for item in batch])
+        return dict(items=items, prev0=False, finish=lambda rec: _scalars(kind, rec))
+    pairs = batch
     live = [j for j, p in enumerate(pairs) if p[0] is not None and p[1] is not None]
-    for j in range(len(pairs)):
-        if j not in live:
-            out[j] = 0.0  # :324-325
-    if not live:
+
+    def fill(values):
+        out = [0.0] * len(pairs)  # a pair with a None frame is 0.0 (:324-325)
+        for j, v in zip(live, values):
+            out[j] = v
         return out
+
+    if not live:
+        return dict(items=None, prev0=False, finish=lambda rec: fill([]))
     chained = all(pairs[live[k]][1] is pairs[live[k - 1]][0] for k in range(1, len(live))) and \
         live == list(range(live[0], live[0] + len(live)))
     if chained:
         # (previous of the first pair, then every current frame) in one pinned buffer: slot 0 is the halo
-        arr = stream.stage_frames(eng, [np.asarray(pairs[live[0]][1])] + [np.asarray(pairs[j][0]) for j in live])
-        rec = eng.complexity(arr[1:], prev0=arr[0], mask=N.M_MOTION, motion_mode=_motion_mode)
-        for j, v in zip(live, _scalars("motion", rec)):
-            out[j] = v
-    else:
-        # arbitrary pairs: interleave (prev, curr) and keep every second result
-        arr = stream.stage_frames(eng, [np.asarray(pairs[j][s]) for j in live for s in (1, 0)])
-        rec = eng.complexity(arr, mask=N.M_MOTION, motion_mode=_motion_mode)
-        for j, v in zip(live, _scalars("motion", rec[1::2])):
-            out[j] = v
-    return out
+        items = [np.asarray(pairs[live[0]][1])] + [np.asarray(pairs[j][0]) for j in live]
+        return dict(items=items, prev0=True, finish=lambda rec: fill(_scalars("motion", rec)))
+    # arbitrary pairs: interleave (prev, curr) and keep every second result
+    items = [np.asarray(pairs[j][s]) for j in live for s in (1, 0)]
+    return dict(items=items, prev0=False, finish=lambda rec: fill(_scalars("motion", rec[1::2])))
 
 
 # ---------------------------------------------------------------------------

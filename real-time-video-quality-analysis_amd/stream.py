@@ -203,11 +203,13 @@ def _upload(engine, dev_ptr, fb, copies, ring_frames=None):
                 engine.h2d_async(dev_ptr + (cp.slot + i) * fb, base + i * step, fb)
 
 
-def stage_frames(engine, items):
-    """A list of equally shaped uint8 frames -> ONE pinned array [n, ...] (process_in_batches' chunk: "whole batch staged
-    in one pinned buffer and dispatched as one launch").  The copier threads gather the frames straight
-    into a slot of the device's pinned ring - no intermediate np.stack.  Valid until the next pass / stage_frames call on
-    the device."""
+def stage_frames_start(engine, items, slot=0, slots=1, min_bytes=0):
+    """Start gathering a list of equally shaped uint8 frames into ONE pinned array [n, ...] (process_in_batches' chunk:
+    "whole batch staged in one pinned buffer and dispatched as one launch") - straight into slot `slot` of
+    `slots` of the device's pinned ring, by the copier threads, no intermediate np.stack.  -> (array, futures); the array is
+    complete once every future has a result and stays valid until the slot is staged into again.  The ring is re-allocated
+    when a slot is too small - never while another slot is in use: a caller that alternates slots passes the largest size it
+    will need as min_bytes on every call."""
     shape = items[0].shape
     for f in items:
         if f.dtype != np.uint8:  # a silent cast would turn float frames in 0..1 into all-zero planes
@@ -216,7 +218,7 @@ def stage_frames(engine, items):
             raise ValueError("the frames of one launch must share a geometry (%s vs %s)" % (f.shape, shape))
     fb = int(np.prod(shape, dtype=np.int64))
     st = _staging_of(engine)
-    blk = st.ring(1, len(items) * fb)[0]
+    blk = st.ring(slots, max(len(items) * fb, int(min_bytes)))[slot]
     out = blk[:len(items) * fb].reshape((len(items),) + shape)
     pool = st.copiers()
     parts = min(STAGE_THREADS, len(items))
@@ -224,7 +226,12 @@ def stage_frames(engine, items):
     def gather(a, b):
         for i in range(a, b):
             np.copyto(out[i], items[i])
-    futs = [pool.submit(gather, len(items) * t // parts, len(items) * (t + 1) // parts) for t in range(parts)]
+    return out, [pool.submit(gather, len(items) * t // parts, len(items) * (t + 1) // parts) for t in range(parts)]
+
+
+def stage_frames(engine, items):
+    """stage_frames_start, waited for: valid until the next pass / staging call on the device."""
+    out, futs = stage_frames_start(engine, items)
     for f in futs:
         f.result()
     return out
