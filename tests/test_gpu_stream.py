@@ -247,3 +247,21 @@ def test_a_failure_inside_a_pass_leaves_the_engines_usable(tmp_path):
     with pytest.raises(N.VqaError):
         vp.frame_quality(tiny, tiny, batch_size=2)
     _same_series(stream.run(dist, complexity=stream.Complexity((64, 64), 2), batch_size=4)[1], want_s)
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_any_number_of_lanes_gives_the_same_bits(lanes, monkeypatch):
+    """stream.MAX_LANES engines alternate a pass's chunks (default 2).  One lane (everything on the default engine, in order)
+    and three (a ring of four slots, three lane buffers) must return what two return."""
+    from rtvqa_amd import stream, synth
+    from rtvqa_amd import video_processing as vp
+    ref = _clip(37, 90, 122, seed=81)
+    dist = synth.distort(ref)
+    q, cx = stream.Quality(vp.bgr_planes(90, 122)), stream.Complexity((64, 64), 3)
+    want_q, want_s = stream.run(dist, ref, q, cx, batch_size=5)
+    monkeypatch.setattr(stream, "MAX_LANES", lanes)
+    dev_r, dev_d = stream.get_engine().upload(ref), stream.get_engine().upload(dist)
+    for r, d in ((ref, dist), (dev_r, dev_d)):
+        got_q, got_s = stream.run(d, r, q, cx, batch_size=5)
+        assert np.array_equal(got_q[0], want_q[0]) and np.array_equal(got_q[1], want_q[1])
+        _same_series(got_s, want_s)
