@@ -265,3 +265,18 @@ def test_any_number_of_lanes_gives_the_same_bits(lanes, monkeypatch):
         got_q, got_s = stream.run(d, r, q, cx, batch_size=5)
         assert np.array_equal(got_q[0], want_q[0]) and np.array_equal(got_q[1], want_q[1])
         _same_series(got_s, want_s)
+
+
+def test_ssim_depends_on_the_batch_size_only_in_the_last_digits():
+    """include/vqa.h, vqa_plane_metrics.ssim: the SSIM map of a plane is summed per row strip and the number of strips follows
+    the launch's workgroup count, so at 1080p the same frame pairs in launches of 3 and of 25 frames may differ in the last
+    digits (<= 1e-8 relative; 1.4e-9 seen here, 6e-10 at 8K) - never in SSE, and never between two runs of the same chunking."""
+    from rtvqa_amd import synth
+    from rtvqa_amd import video_processing as vp
+    ref = _clip(25, 1080, 1920, seed=91)
+    dist = synth.distort(ref)
+    a = vp.frame_quality(ref, dist, batch_size=25)
+    b = vp.frame_quality(ref, dist, batch_size=3)
+    b2 = vp.frame_quality(ref, dist, batch_size=3)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(b[0], b2[0]) and np.array_equal(b[1], b2[1])
+    assert np.max(np.abs(a[1] - b[1]) / a[1]) <= 1e-8
