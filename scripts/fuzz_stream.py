@@ -50,6 +50,31 @@ for case in range(n_cases):
     if cx:
         for k in KINDS:
             assert len(got_s[k]) == len(want_s[k]) and all((x == y) or (x != x and y != y) for x, y in zip(got_s[k], want_s[k])), (k, ctx)
+    if case % 4 == 0:
+        # the quality half on the other layouts (gray planes, planar yuv420p with odd sizes) and FFmpeg's integer SSIM, from
+        # pageable and pinned memory: chunked against one chunk
+        from rtvqa_amd import frames as fr_, video_processing as vp
+        lay = ("gray", "yuv420p")[case // 4 % 2]
+        mode = ("gauss", "ffmpeg")[case // 8 % 2]
+        hh, ww = max(h, 16), max(w, 16)
+        if lay == "gray":
+            qa, qb = np.ascontiguousarray(ref[..., 0]), np.ascontiguousarray(dist[..., 0])
+            if (hh, ww) != (h, w):
+                qa, qb = np.pad(qa, ((0, 0), (0, hh - h), (0, ww - w))), np.pad(qb, ((0, 0), (0, hh - h), (0, ww - w)))
+        else:
+            pr = np.pad(ref, ((0, 0), (0, hh - h), (0, ww - w), (0, 0))) if (hh, ww) != (h, w) else ref
+            pd = np.pad(dist, ((0, 0), (0, hh - h), (0, ww - w), (0, 0))) if (hh, ww) != (h, w) else dist
+            qa, qb = fr_.bgr_to_yuv420p(pr), fr_.bgr_to_yuv420p(pd)
+            if min((hh + 1) // 2, (ww + 1) // 2) < 11:
+                mode = "ffmpeg" if min((hh + 1) // 2, (ww + 1) // 2) >= 8 else None
+        if mode:
+            one = vp.frame_quality(qa, qb, lay, mode, hh, ww, engine=eng, batch_size=10 ** 6)
+            pa, pb = eng.alloc_pinned(qa.shape), eng.alloc_pinned(qb.shape)
+            pa[...], pb[...] = qa, qb
+            for x, y in ((qa, qb), (pa, pb)):
+                got = vp.frame_quality(x, y, lay, mode, hh, ww, batch_size=batch)
+                assert np.array_equal(got[0], one[0]) and np.array_equal(got[1], one[1]), ("layout", lay, mode, (case, n, hh, ww, batch))
+            eng.free_pinned(pa); eng.free_pinned(pb)
     for p in keep:
         eng.free_pinned(p)
     if res == 4:
