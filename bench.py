@@ -456,12 +456,18 @@ def kernel_report(prof, alg_bytes, valu_fma, mfma_flops, workload, frames_per_la
 
 
 # ---------------------------------------------------------------------------
+API_LABELS = ("Advanced Motion Complexity", "DCT Complexity", "Temporal DCT Complexity", "Histogram Complexity",
+              "Edge Detection Complexity", "ORB Feature Complexity", "Color Histogram Complexity", "Framerate Variation")
+# (the reference unpacks the 8-tuple under these names in THIS order, video_processing.py:235-242 - which shifts five labels
+#  against the tuple's real order, complexity_metrics.py:301-310; reading the row back in label order recovers the tuple)
+
+
 def api_rates(vp, cm, clips, config, steps, frames):
     """process_video_and_extract_metrics (the reference's caller of run_ffmpeg_metrics + calculate_average_scene_complexity,
     video_processing.py:216, :242) on the same clip held three ways; one warm call (allocations, the pinned ring), then
-    `steps` timed calls each.  -> {name_fps: ...}, last metrics dict"""
+    `steps` timed calls each.  -> {name_fps: ...}, {name: the last call's row}"""
     import tempfile
-    out, metrics = {}, None
+    out, rows = {}, {}
     with tempfile.TemporaryDirectory() as tmp:
         csv = os.path.join(tmp, "bench_api.csv")
         for name, (r, d) in clips.items():
@@ -470,10 +476,34 @@ def api_rates(vp, cm, clips, config, steps, frames):
             for _ in range(steps):
                 metrics = vp.process_video_and_extract_metrics(r, d, config, csv_file=csv)
             out[name + "_fps"] = round(frames * steps / (time.perf_counter() - t0), 1)
-    return out, metrics
+            rows[name] = metrics
+    return out, rows
 
 
-def api_end_to_end(rtvqa_amd, eng, ref_dev, dist_dev, ref_pin, dist_pin, h, w, steps, value, e2e_fps, config=None):
+def api_rows_check(cm, rows, crec, dist_clip):
+    """The rows the entry point returned, against the C ABI's own (oracle-verified) records of the same frames: the last timed
+    step measured frames 1..B of the clip against frames 0..B-1 - exactly the samples of the clip at frame_interval 1 - so
+    pooling its records through the reference's tails must give the row's eight complexity values (counts and integer-derived
+    values exactly, float sums to 1e-12: the entry point launches <= 100 frames at a time, the step 256), and the three
+    residences must agree with each other to the last bit."""
+    from rtvqa_amd import tails
+    series = {k: tails.scalars(k, crec) for k in ("motion", "dct", "hist", "edge", "orb", "color")}
+    series["temporal"] = tails.scalars("temporal", crec)[1:]
+    want = cm.pool_series(series, dist_clip, 1)
+    bad = []
+    names = list(rows)
+    for name in names:
+        got = [rows[name][lab] for lab in API_LABELS]
+        for k, (g, wv) in enumerate(zip(got, want)):
+            g, wv = float(g), float(wv)
+            if not ((g != g and wv != wv) or abs(g - wv) <= 1e-12 * max(abs(wv), 1e-300)):
+                bad.append("%s tuple[%d] %.17g vs %.17g" % (name, k, g, wv))
+        if any(rows[name][lab] != rows[names[0]][lab] for lab in API_LABELS + ("PSNR", "SSIM")):
+            bad.append("%s differs from %s" % (name, names[0]))
+    return bad
+
+
+def api_end_to_end(rtvqa_amd, eng, ref_dev, dist_dev, ref_pin, dist_pin, h, w, steps, value, e2e_fps, config=None, crec=None):
     """The drop-in Python surface on the measured path: resident / pinned host / pageable host clip of the workload's
     geometry through process_video_and_extract_metrics.  Measured after the timed region; never `value`."""
     from rtvqa_amd import complexity_metrics as cm
@@ -481,13 +511,22 @@ def api_end_to_end(rtvqa_amd, eng, ref_dev, dist_dev, ref_pin, dist_pin, h, w, s
     n = dist_pin.shape[0]
     config = config or {"crf": 23, "resize_width": w, "resize_height": h, "frame_interval": 1, "batch_size": 100}
     ref_pg, dist_pg = np.array(ref_pin), np.array(dist_pin)  # ordinary (pageable) copies, as a caller that decoded a file holds them
-    rates, m = api_rates(vp, cm, {"resident": (ref_dev, dist_dev), "host_pinned": (ref_pin, dist_pin),
-                                  "host_pageable": (ref_pg, dist_pg)}, config, steps, n)
+    rates, rows = api_rates(vp, cm, {"resident": (ref_dev, dist_dev), "host_pinned": (ref_pin, dist_pin),
+                                     "host_pageable": (ref_pg, dist_pg)}, config, steps, n)
     cm.release_buffers()  # the pinned ring and lane buffers of the passes: given back (stream.release_buffers)
+    m = rows["resident"]
     out = dict(rates, frames_per_call=n, calls=steps, config=config,
                entry_point="rtvqa_amd.video_processing.process_video_and_extract_metrics (= run_ffmpeg_metrics + "
                            "calculate_average_scene_complexity in ONE pass; stats files, regex parse and CSV row included)",
                PSNR=m.get("PSNR"), SSIM=m.get("SSIM"))
+    if crec is not None:
+        bad = api_rows_check(cm, rows, crec, dist_dev)
+        out["verified"] = {"ok": not bad, "checker": "the C ABI's last timed step (itself verified against the oracle) pooled through the "
+                                                     "reference's tails: the row's eight complexity values to 1e-12, the three residences bit for bit"}
+        if bad:
+            sys.stderr.write("[bench] FATAL: the entry point's row differs from the C ABI's records: %s\n" % json.dumps(bad[:8]))
+            sys.stderr.flush()
+            os._exit(4)
     if value:
         out["resident_vs_value"] = round(rates["resident_fps"] / value, 3)
     if e2e_fps:
@@ -729,8 +768,12 @@ def main_c1(args, rank, local_rank, world):
                 "row": {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in metrics.items()
                         if k in ("PSNR", "SSIM", "Resolution (px)")}}
         if args.api_steps > 0:
-            rates, _m = api_rates(vp, cm, {"host_pinned": (ref_pin, dist_pin), "host_pageable": (ref_h, dist_h)}, cfg, args.api_steps, n)
-            line["api_end_to_end"] = dict(rates, resident_fps=round(value / world, 1), frames_per_call=n, calls=args.api_steps,
+            rates, rows = api_rates(vp, cm, {"host_pinned": (ref_pin, dist_pin), "host_pageable": (ref_h, dist_h)}, cfg, args.api_steps, n)
+            same = all(rows[k][lab] == metrics[lab] for k in rows for lab in API_LABELS + ("PSNR", "SSIM"))
+            if not same:
+                sys.stderr.write("[bench] FATAL: c1 rows from host memory differ from the resident clip's row\n")
+                os._exit(4)
+            line["api_end_to_end"] = dict(rates, rows_identical_to_resident=same, resident_fps=round(value / world, 1), frames_per_call=n, calls=args.api_steps,
                                           bytes_per_frame=2 * 3 * P,
                                           note="the same call from host memory: both 1080p streams cross PCIe once (12.4 MB per frame "
                                                "pair), the complexity kernels read every 10th frame of the uploaded chunk")
@@ -1126,7 +1169,8 @@ def main():
                                                 params, planes, smode, args.e2e_steps, yref_pin, ydist_pin)
             if do_api:
                 line["api_end_to_end"] = api_end_to_end(rtvqa_amd, eng, ref_all, dist_all, ref_pin, dist_pin, h, w, args.api_steps,
-                                                        value, line.get("end_to_end", {}).get("fps"))
+                                                        value, line.get("end_to_end", {}).get("fps"),
+                                                        crec=c if (args.verify and args.steps > 0) else None)
             elif rank == 0 and args.api_steps > 0:
                 line["api_end_to_end"] = None  # (c2 / non-default modes: process_video_and_extract_metrics runs the default full suite)
             if cpu_line is not None:
