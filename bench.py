@@ -523,10 +523,9 @@ def api_end_to_end(rtvqa_amd, eng, ref_dev, dist_dev, ref_pin, dist_pin, h, w, s
         bad = api_rows_check(cm, rows, crec, dist_dev)
         out["verified"] = {"ok": not bad, "checker": "the C ABI's last timed step (itself verified against the oracle) pooled through the "
                                                      "reference's tails: the row's eight complexity values to 1e-12, the three residences bit for bit"}
-        if bad:
+        if bad:  # (the caller prints no line and exits 4 after the ranks' final barrier: no rank is left hanging)
             sys.stderr.write("[bench] FATAL: the entry point's row differs from the C ABI's records: %s\n" % json.dumps(bad[:8]))
             sys.stderr.flush()
-            os._exit(4)
     if value:
         out["resident_vs_value"] = round(rates["resident_fps"] / value, 3)
     if e2e_fps:
@@ -743,6 +742,7 @@ def main_c1(args, rank, local_rank, world):
     dt, devices = reduce_over_ranks(td if dist_on else None, dt, [float(metrics.get("SSIM", 0.0)), float(metrics["DCT Complexity"]), float(n)],
                                     device, world, rehearsal, False, red_dev)
     value = n * args.steps * world / dt if args.steps > 0 else 0.0
+    c1_bad = False
     if rank == 0:
         P = h * w
         fpl = float(n) / max(1, -(-n // cfg["batch_size"]))  # frame pairs per quality launch (chunks of batch_size)
@@ -772,7 +772,7 @@ def main_c1(args, rank, local_rank, world):
             same = all(rows[k][lab] == metrics[lab] for k in rows for lab in API_LABELS + ("PSNR", "SSIM"))
             if not same:
                 sys.stderr.write("[bench] FATAL: c1 rows from host memory differ from the resident clip's row\n")
-                os._exit(4)
+                c1_bad = True
             line["api_end_to_end"] = dict(rates, rows_identical_to_resident=same, resident_fps=round(value / world, 1), frames_per_call=n, calls=args.api_steps,
                                           bytes_per_frame=2 * 3 * P,
                                           note="the same call from host memory: both 1080p streams cross PCIe once (12.4 MB per frame "
@@ -781,13 +781,16 @@ def main_c1(args, rank, local_rank, world):
             line["cpu_baseline"] = cpu_line
         if verified is not None:
             line["verified"] = verified
-        print(json.dumps(line), flush=True)
+        if not c1_bad:  # no JSON line for a run whose output is wrong
+            print(json.dumps(line), flush=True)
     if dist_on:
         td.barrier()
         td.destroy_process_group()
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     cm.release_buffers()
+    if c1_bad:
+        os._exit(4)
 
 
 # ---------------------------------------------------------------------------
@@ -1094,6 +1097,7 @@ def main():
                                     device, world, rehearsal, stub, red_dev)
     frames_total = B * args.steps * world
     value = frames_total / dt if args.steps > 0 else 0.0
+    api_bad = False
 
     if rank == 0:
         line = {
@@ -1177,12 +1181,16 @@ def main():
                 line["cpu_baseline"] = cpu_line
             if verified is not None:
                 line["verified"] = verified
-            print(json.dumps(line), flush=True)
+            api_bad = ((line.get("api_end_to_end") or {}).get("verified") or {}).get("ok") is False
+            if not api_bad:  # no JSON line for a run whose output is wrong
+                print(json.dumps(line), flush=True)
     if dist_on:
         td.barrier()
         td.destroy_process_group()
     for e in reversed(all_engs):
         e.close()
+    if api_bad:
+        os._exit(4)
 
 
 if __name__ == "__main__":
