@@ -176,3 +176,75 @@ def check(status, where, ctx=None):
         if ctx is not None and status in (VQA_ERR_HIP, VQA_ERR_OOM):
             detail = load().vqa_last_hip_error(ctx).decode()
         raise VqaError(status, where, detail)
+
+
+# ---------------------------------------------------------------------------
+# roctx ranges (SURVEY.md section 5 "Tracing": rocprofv3 --marker-trace): named ranges around the host-side stages of a pass,
+# so a trace shows gather / upload / submit / wait / tails per chunk and lane next to the kernels and copies.  The marker
+# library is looked for only when a profiler is attached (rocprofv3 preloads its tool library) or VQA_ROCTX=1 asks for it;
+# everywhere else - and when the library is absent - trace_range() is a no-op that costs one attribute test.
+# ---------------------------------------------------------------------------
+_roctx = None
+
+
+def _roctx_wanted():
+    v = os.environ.get("VQA_ROCTX")
+    if v is not None:
+        return v not in ("", "0")
+    return "rocprofiler" in os.environ.get("LD_PRELOAD", "") or "ROCP_TOOL_LIBRARIES" in os.environ
+
+
+def _roctx_load():
+    global _roctx
+    if _roctx is None:
+        _roctx = False
+        if _roctx_wanted():
+            for name in ("librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"):
+                for where in ("", "/opt/rocm/lib/"):
+                    try:
+                        lib = C.CDLL(where + name)
+                        lib.roctxRangePushA.argtypes = [C.c_char_p]
+                        lib.roctxRangePushA.restype = C.c_int
+                        lib.roctxRangePop.restype = C.c_int
+                        _roctx = lib
+                        return _roctx
+                    except (OSError, AttributeError):
+                        continue
+    return _roctx
+
+
+class _Range:
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _roctx.roctxRangePushA(self.name)
+
+    def __exit__(self, *a):
+        _roctx.roctxRangePop()
+        return False
+
+
+class _NoRange:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_RANGE = _NoRange()
+
+
+def trace_range(name, *args):
+    """with trace_range("vqa:upload k=%d lane=%d", k, lane): ... - a roctx range when markers are on, else nothing"""
+    lib = _roctx if _roctx is not None else _roctx_load()
+    if not lib:
+        return _NO_RANGE
+    return _Range((name % args if args else name).encode())
+
+
+def roctx_active():
+    return bool(_roctx if _roctx is not None else _roctx_load())

@@ -163,7 +163,8 @@ def _one(kind, frame, resize_width, resize_height):
     if frame.ndim == 2:  # gray input: B=G=R=v makes cvtColor the identity (3735+19235+9798 = 2^15)
         frame = np.repeat(frame[..., None], 3, axis=2)
     eng = get_engine()
-    rec = eng.complexity(frame[None], mask=_MASK[kind], resize=(resize_width, resize_height))
+    with stream.pass_lock(eng.device):
+        rec = eng.complexity(frame[None], mask=_MASK[kind], resize=(resize_width, resize_height))
     return _scalar(kind, rec[0])
 
 
@@ -194,8 +195,9 @@ def process_frame_complexity(frame_pair):
     if frame is None or prev_frame is None:
         return 0.0
     eng = get_engine()
-    rec = eng.complexity(np.asarray(frame)[None], prev0=np.asarray(prev_frame), mask=N.M_MOTION,
-                         motion_mode=_motion_mode)
+    with stream.pass_lock(eng.device):
+        rec = eng.complexity(np.asarray(frame)[None], prev0=np.asarray(prev_frame), mask=N.M_MOTION,
+                             motion_mode=_motion_mode)
     return _scalar("motion", rec[0])
 
 
@@ -204,7 +206,8 @@ def process_temporal_dct_frame(prev_gray_frame, curr_gray_frame, resize_width, r
     prev3 = np.repeat(np.asarray(prev_gray_frame)[..., None], 3, axis=2)
     curr3 = np.repeat(np.asarray(curr_gray_frame)[..., None], 3, axis=2)
     eng = get_engine()
-    rec = eng.complexity(curr3[None], prev0=prev3, mask=N.M_TEMPORAL_DCT, resize=(resize_width, resize_height))
+    with stream.pass_lock(eng.device):
+        rec = eng.complexity(curr3[None], prev0=prev3, mask=N.M_TEMPORAL_DCT, resize=(resize_width, resize_height))
     return _scalar("temporal", rec[0])
 
 
@@ -214,7 +217,9 @@ def process_orb_frame_for_parallel(frame):
     frame = np.asarray(frame)
     if frame.ndim == 2:
         frame = np.repeat(frame[..., None], 3, axis=2)
-    rec = get_engine().complexity(frame[None], mask=N.M_ORB)
+    eng = get_engine()
+    with stream.pass_lock(eng.device):
+        rec = eng.complexity(frame[None], mask=N.M_ORB)
     return _scalar("orb", rec[0])
 
 
@@ -250,45 +255,57 @@ def process_in_batches(frames, process_func, num_workers, batch_size=100, **kwar
             results.extend(call(item) for item in frames[i:i + batch_size])
         return results
     eng = get_engine()
+    with stream.pass_lock(eng.device):  # the ring, the default engine's pending state: one pass at a time per device
+        return _batched_map(eng, kind, frames, process_func, batch_size, kw, kwargs)
+
+
+def _batched_map(eng, kind, frames, process_func, batch_size, kw, kwargs):
+    """process_in_batches' kernel branch: every chunk is ONE pinned buffer (gathered by the copier threads), ONE asynchronous
+    upload, ONE launch - and while chunk k crosses PCIe and runs, the copiers gather chunk k + 1 into the ring's other slot."""
+    results = []
     resize = None if kind in ("orb", "motion") else (kw["resize_width"], kw["resize_height"])
     params = eng.make_params(resize=resize, motion_mode=_motion_mode)
     call = functools.partial(process_func, **kwargs)
     chunks = [_chunk_job(kind, frames[i:i + batch_size], call) for i in range(0, len(frames), batch_size)]
     # the ring's two slots are sized ONCE for the largest chunk (a slot is never re-allocated while its neighbour is in flight)
     slot_bytes = max([sum(int(f.nbytes) for f in c["items"]) for c in chunks if c["items"]] or [0])
+    fills = []  # copier futures that may still be writing into the ring
 
     def start(k):
         c = chunks[k]
-        return stream.stage_frames_start(eng, c["items"], slot=k & 1, slots=2, min_bytes=slot_bytes) if c["items"] else None
+        if not c["items"]:
+            return None
+        arr, futs = stream.stage_frames_start(eng, c["items"], slot=k & 1, slots=2, min_bytes=slot_bytes)
+        fills.extend(futs)
+        return arr, futs
 
-    # Every chunk is ONE pinned buffer (gathered by the copier threads), ONE asynchronous upload, ONE launch - and while
-    # chunk k crosses PCIe and runs, the copiers gather chunk k + 1 into the ring's other slot.
-    nxt = start(0) if chunks else None
-    for k, c in enumerate(chunks):
-        cur = nxt
-        if cur is None:  # nothing to launch (frames of different sizes: per-item map; a chunk of None pairs: zeros)
-            results.extend(c["finish"](None))
-            nxt = start(k + 1) if k + 1 < len(chunks) else None
-            continue
-        arr, futs = cur
-        for f in futs:
-            f.result()
-        try:
+    try:
+        nxt = start(0) if chunks else None
+        for k, c in enumerate(chunks):
+            cur = nxt
+            if cur is None:  # nothing to launch (frames of different sizes: per-item map; a chunk of None pairs: zeros)
+                results.extend(c["finish"](None))
+                nxt = start(k + 1) if k + 1 < len(chunks) else None
+                continue
+            arr, futs = cur
+            for f in futs:
+                f.result()
+            fills[:] = [f for f in fills if not f.done()]
             if c["prev0"]:
                 eng.complexity_submit(arr[1:], arr[0], _MASK[kind], params)
             else:
                 eng.complexity_submit(arr, None, _MASK[kind], params)
             nxt = start(k + 1) if k + 1 < len(chunks) else None
             rec = eng.complexity_wait()
-        except BaseException:
-            eng.drain()
-            for f in (nxt[1] if nxt else ()):  # (the copiers of the next chunk: the ring must be quiet when the error surfaces)
-                try:
-                    f.result()
-                except Exception:
-                    pass
-            raise
-        results.extend(c["finish"](rec))
+            results.extend(c["finish"](rec))
+    except BaseException:
+        for f in fills:  # (every copier of this call: the ring must be quiet when the error surfaces)
+            try:
+                f.result()
+            except BaseException:
+                pass
+        eng.drain()
+        raise
     return results
 
 
@@ -329,7 +346,7 @@ def _chunk_job(kind, batch, call):
 # the aggregator
 # ---------------------------------------------------------------------------
 def complexity_series(video, resize_width, resize_height, frame_interval=10, batch_size=100, engine=None,
-                      dct_mode=N.DCT_AUTO, mask=N.M_ALL, shard=None):
+                      dct_mode=N.DCT_AUTO, mask=N.M_ALL, shard=None, motion=None, device=None):
     """Per-frame series for the frames the reference measures, from ONE fused pass (stream.run).
 
     Returns dict kind -> list, each in the reference's sample order:
@@ -338,11 +355,22 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
     shard=(rank, world): only this rank's contiguous range of the T-1 samples is computed (the
     shard also reads the ONE selected frame before its first, as the pair metrics' halo); the lists then hold
     that range only and out["range"] = (lo, hi) gives its place in the whole series.
+    motion: "sad" / "farneback" (None: set_motion_mode's / VQA_MOTION's choice); device: the GPU of a host clip's pass
+    (None: VQA_DEVICE, else LOCAL_RANK, else 0) - the config keys of the same names.
     Chunks of up to batch_size samples alternate between two engines of the device (one with Farneback motion: its
     scratch is GiB-sized per context); only the selected frames of a host clip cross PCIe, from the caller's pinned
     memory or through the pinned ring."""
-    cx = stream.Complexity((resize_width, resize_height), frame_interval, mask, dct_mode, _motion_mode, shard)
-    return stream.run(_open_frames(video), complexity=cx, batch_size=batch_size, engine=engine)[1]
+    cx = stream.Complexity((resize_width, resize_height), frame_interval, mask, dct_mode, motion_mode_of(motion), shard)
+    return stream.run(_open_frames(video), complexity=cx, batch_size=batch_size, engine=engine, device=device)[1]
+
+
+def motion_mode_of(motion=None):
+    """"sad" / "farneback" / None (the module's current mode) -> the C ABI's constant"""
+    if motion is None:
+        return _motion_mode
+    if motion not in _MOTION_MODES:
+        raise ValueError("motion must be 'sad' or 'farneback'.")
+    return _MOTION_MODES[motion]
 
 
 _DCT_MODES = {None: N.DCT_AUTO, "auto": N.DCT_AUTO, "full": N.DCT_FULL, "block8": N.DCT_BLOCK8}
@@ -378,13 +406,15 @@ def pool_series(s, video_path, frame_interval=10, smoothing_factor=0.8, num_work
 
 def calculate_average_scene_complexity(video_path, resize_width, resize_height, frame_interval=10,
                                        smoothing_factor=0.8, num_workers=None, batch_size=100, fps=30.0,
-                                       dct_mode=None):
+                                       dct_mode=None, motion=None, device=None):
     """complexity_metrics.py:246-310.  Returns the 8-tuple in the reference's order (:301-310):
     (motion, dct, histogram, edge, orb, colour_histogram, temporal_dct, framerate_variation).
     `video_path` may be a .npy path, an ndarray [N,H,W,3] or DeviceFrames; `fps` stands in for the container's
-    timestamps (:66) and `dct_mode` is as for calculate_temporal_dct."""
+    timestamps (:66); `dct_mode` is as for calculate_temporal_dct, `motion` / `device` as for complexity_series."""
+    if dct_mode not in _DCT_MODES:
+        raise ValueError("dct_mode must be 'auto', 'block8' or 'full'.")
     s = complexity_series(video_path, resize_width, resize_height, frame_interval, batch_size,
-                          dct_mode=_DCT_MODES[dct_mode])
+                          dct_mode=_DCT_MODES[dct_mode], motion=motion, device=device)
     return pool_series(s, video_path, frame_interval, smoothing_factor, num_workers, batch_size, fps)
 
 

@@ -95,8 +95,17 @@ class _Staging:
             for a in self.slots:
                 self.engine.free_pinned(a)
             self.slots = []
-            self.slot_bytes = max(nbytes, self.slot_bytes)
-            self.slots = [self.engine.alloc_pinned((self.slot_bytes,)) for _ in range(count)]
+            want = max(nbytes, self.slot_bytes)
+            self.slot_bytes = 0
+            fresh = []
+            try:
+                for _ in range(count):
+                    fresh.append(self.engine.alloc_pinned((want,)))
+            except BaseException:  # a half-built ring is given back whole: nothing leaks, the next pass starts from an empty ring
+                for a in fresh:
+                    self.engine.free_pinned(a)
+                raise
+            self.slots, self.slot_bytes = fresh, want
         return self.slots[:count]
 
     def device_buffer(self, lane, name, nbytes):
@@ -135,13 +144,18 @@ def _staging_of(engine):
 def release_buffers(device=None):
     """Give back what the passes keep between calls on `device` (all devices when None): the pinned ring, the lane
     buffers on the device and - vqa_trim - every engine's scratch and cached tables.  The reference holds nothing
-    between calls (a process pool per call, complexity_metrics.py:143-147); the next call re-grows what it needs."""
+    between calls (a process pool per call, complexity_metrics.py:143-147); the next call re-grows what it needs.
+    Waits for a pass that is running on the device (pass_lock)."""
     with _lock:
         devs = [device] if device is not None else sorted(set(_staging) | set(_engines))
-        for d in devs:
-            if d in _staging:
-                _staging.pop(d).release()
-            for e in ([_engines[d]] if d in _engines else []) + list(_second.get(d, ())):
+    for d in devs:
+        with pass_lock(d):
+            with _lock:
+                st = _staging.pop(d, None)
+                engs = ([_engines[d]] if d in _engines else []) + list(_second.get(d, ()))
+            if st is not None:
+                st.release()
+            for e in engs:
                 e.trim()
 
 
@@ -245,36 +259,49 @@ def selected_indices(num_frames, frame_interval):
     return np.arange(frame_interval - 1, num_frames, frame_interval)
 
 
-def plan_chunks(n, want_q, interval, lo, hi, cap):
+def plan_chunks(n, want_q, interval, lo, hi, cap, split=False):
     """The chunks of a pass, as pure arithmetic (no engine, no frames): -> list of dicts.
 
     n frames; quality wanted or not; complexity samples lo..hi-1 of the series at `interval` (None: no complexity), where
     sample j measures selected frame idx[1 + j] against idx[j], idx = selected_indices(n, interval); `cap` frames per chunk.
     A chunk's frames sit in a buffer of cap + 1 frame slots, slot 0 being the halo (the frame before the chunk's first
     sample when it lies before the chunk).  Per chunk:
-      q0, qn        quality: source frames q0 .. q0 + qn - 1, in slots 1 .. qn           (quality passes)
+      q0, qn        quality: source frames q0 .. q0 + qn - 1, in slots qslot .. qslot + qn - 1     (quality passes)
       j0, j1        complexity samples j0 .. j1 - 1; their frames sit in slots 1 + first + i * step, prev0 in slot
                     1 + prev_slot (prev_slot = -1: the halo slot)
       copies        (slot, first source frame, count, source step) of the distorted stream; rcopies: of the reference
     With quality the chunk is the dense source range [q0, q0 + qn) and the samples are every interval-th frame of it;
-    without, the chunk holds exactly the samples' frames (compact), so only selected frames ever move."""
+    without, the chunk holds exactly the samples' frames (compact), so only selected frames ever move.
+    split: the quality kernels read their OWN pair of streams (planar yuv420p, what FFmpeg's filters compare,
+    video_processing.py:274-276) and the complexity kernels the encoded stream as cv2 decodes it (BGR,
+    complexity_metrics.py:100): `rcopies` / `qcopies` are the dense range of the quality pair (slots 0 .. qn - 1, qslot = 0)
+    and `copies` the chunk's samples of the BGR stream, compact - every byte of either stream moves once."""
     plans = []
     if want_q:
         idx = selected_indices(n, interval) if interval else None
         for k, a in enumerate(range(0, n, cap)):
             b = min(a + cap, n)
-            p = dict(k=k, q0=a, qn=b - a, j0=0, j1=0, copies=[], rcopies=[(0, a, b - a, 1)])
+            p = dict(k=k, q0=a, qn=b - a, qslot=0 if split else 1, j0=0, j1=0, copies=[], rcopies=[(0, a, b - a, 1)])
+            if split:
+                p["qcopies"] = [(0, a, b - a, 1)]
             if interval and hi > lo:
                 # samples whose frame lies in [a, b): sample j measures selected frame idx[1 + j]
                 j0 = max(lo, int(np.searchsorted(idx, a)) - 1, 0)
                 j1 = max(j0, min(hi, int(np.searchsorted(idx, b)) - 1))
                 p.update(j0=j0, j1=j1)
-                if j1 > j0:
+                if j1 > j0 and split:
+                    p.update(first=0, step=1, prev_slot=-1)
+                    if interval == 1:
+                        p["copies"].append((0, int(idx[j0]), j1 - j0 + 1, 1))
+                    else:
+                        p["copies"] += [(0, int(idx[j0]), 1, 1), (1, int(idx[1 + j0]), j1 - j0, interval)]
+                elif j1 > j0:
                     prev = int(idx[j0])
                     p.update(first=int(idx[1 + j0]) - a, step=interval, prev_slot=(prev - a) if prev >= a else -1)
                     if prev < a:
                         p["copies"].append((0, prev, 1, 1))
-            p["copies"].append((1, a, b - a, 1))
+            if not split:
+                p["copies"].append((1, a, b - a, 1))
             plans.append(p)
         return plans
     idx = selected_indices(n, interval)
@@ -304,23 +331,77 @@ class Quality:
         self.planes, self.ssim_mode = planes, ssim_mode
 
 
-def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=None, on_quality=None):
+class _Feed:
+    """One stream of a pass on its way to the kernels: its source and, for a host source, the lane buffers and the region
+    of a ring slot its chunks travel through.  `key` names the plan's copy list for it."""
+
+    def __init__(self, name, key, frames, engine):
+        self.name, self.key = name, key
+        self.src = _Source(frames, engine)
+        self.fb = self.src.fb
+        self.host = self.src.kind != "device"
+        self.staged = self.src.kind == "pageable"
+        self.slots = 0      # frame slots a chunk of this feed needs (from the plans)
+        self.ring_off = 0   # byte offset of the feed's region inside a ring slot
+
+    def geometry(self):
+        f = self.src.frames
+        return (f.h, f.w, f.channels) if isinstance(f, DeviceFrames) else tuple(f.shape[1:])
+
+
+# One pass at a time per device: the pinned ring, the lane buffers and the engines' pending state are per device, and the
+# reference's surface is written for threaded callers (video_processing.py:25-41 queue logging, :41,:62-67 CSV lock).  Every
+# entry that touches them (run, process_in_batches' kernel branch, the per-frame callables, release_buffers) holds this.
+_pass_locks = {}
+
+
+def pass_lock(device=None):
+    """The re-entrant lock that serialises passes on `device` (default device when None)."""
+    if device is None:
+        device = int(os.environ.get("VQA_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _lock:
+        lk = _pass_locks.get(device)
+        if lk is None:
+            lk = _pass_locks[device] = threading.RLock()
+        return lk
+
+
+def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=None, on_quality=None, qdist=None, device=None):
     """One pass over a clip.
 
-    dist        the stream both halves read: [N,H,W,3] uint8 BGR (host array, memmap or DeviceFrames); for a
-                quality-only pass any [N, frame_bytes] layout the planes describe
-    ref         the reference stream of the quality half (same layout), or None
+    dist        the stream the complexity half reads: [N,H,W,3] uint8 BGR (host array, memmap or DeviceFrames); without
+                `qdist` the quality half reads it too (for a quality-only pass any [N, frame_bytes] layout the planes describe)
+    ref         the reference stream of the quality half (same layout as the distorted stream it is compared with), or None
+    qdist       the distorted stream AS THE QUALITY FILTERS SEE IT when that is not `dist`: planar yuv420p [N, H*W*3/2] next to
+                the encoded BGR stream (the reference compares decoded planes with FFmpeg, video_processing.py:274-276, and
+                measures complexity on cv2's BGR decode of the same encoded file, :242-247).  Still ONE pass: per chunk the
+                quality pair and the chunk's selected BGR frames are uploaded, each byte once
     quality     Quality or None;  complexity  Complexity or None
     on_quality  optional callback(first_frame, sse [m,p], ssim [m,p]) per finished chunk, in frame order (stats
                 lines are formatted while the GPU works on the next chunk)
+    device      the device of the default engine when `engine` is None and no stream is resident (config key "device")
     -> (sse [n,p] uint64, ssim [n,p] float64) or None, series dict or None.
     series: kind -> list in the reference's sample order (motion/dct/hist/edge/orb/color: T-1 samples, temporal:
-    T-2, complexity_metrics.py:268-290, :533-537) and "range" = the shard's place in the whole series."""
+    T-2, complexity_metrics.py:268-290, :533-537) and "range" = the shard's place in the whole series.
+    Streams may live in different places (device / pinned / pageable): each travels its own way.  Passes on one device
+    are serialised (pass_lock): a second thread's call waits for the first to finish."""
     want_q, want_c = quality is not None, complexity is not None
+    if qdist is not None and not (want_q and want_c):
+        if want_q:          # a quality-only pass compares the quality pair; the BGR stream has no reader
+            dist = qdist
+        qdist = None
+    split = qdist is not None
+    qd = qdist if split else dist       # the distorted stream of the quality half
+
+    def count(fr):
+        return fr.n if isinstance(fr, DeviceFrames) else fr.shape[0]
+
     on_device = isinstance(dist, DeviceFrames)
-    n = dist.n if on_device else dist.shape[0]
     if want_c and (dist.channels != 3 if on_device else (dist.ndim != 4 or dist.shape[3] != 3)):
         raise ValueError("frames must be uint8 [N,H,W,3] packed BGR")
+    n = count(qd) if want_q else count(dist)
+    if split and count(dist) != n:
+        raise ValueError("the quality pair and the encoded stream must have the same number of frames (%d vs %d)" % (n, count(dist)))
     series = None
     if want_c:
         cx = complexity
@@ -338,20 +419,52 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
     if n == 0:
         e = np.zeros((0, len(quality.planes)))
         return (e.astype(np.uint64), e), series
-    first = engine or get_engine(_device_of(dist))
-    src = _Source(dist, first)
-    rsrc = _Source(ref, first) if want_q else None
-    if want_q and (rsrc.n != src.n or rsrc.fb != src.fb or (rsrc.kind == "device") != (src.kind == "device")):
-        raise ValueError("reference and distorted streams must have the same frame count, layout and residence")
+    if engine is not None:
+        first = engine
+    else:
+        dev = next((d for d in (_device_of(f) for f in (dist, ref, qdist) if f is not None) if d is not None), device)
+        first = get_engine(dev)
+    with pass_lock(first.device):
+        return _run_locked(first, engine, dist, ref, qd, split, quality, complexity if want_c else None, series, n,
+                           batch_size, on_quality)
 
-    fb = src.fb
+
+def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series, n, batch_size, on_quality):
+    want_q, want_c = quality is not None, complexity is not None
+    feeds = {}
+    if want_c or not split:
+        feeds["dist"] = _Feed("dist", "copies", dist, first)
+    if want_q:
+        feeds["ref"] = _Feed("ref", "rcopies", ref, first)
+        if split:
+            feeds["qdist"] = _Feed("qdist", "qcopies", qd, first)
+        fq, fr = feeds["qdist" if split else "dist"], feeds["ref"]
+        if fr.src.n != fq.src.n or fr.fb != fq.fb:
+            raise ValueError("reference and distorted streams must have the same frame count and layout")
+        if fr.geometry() != fq.geometry() and not (fr.host != fq.host):
+            # (an equal-byte reshape - 1080x1920 against 1920x1080 - would be compared plane against garbage)
+            raise ValueError("reference and distorted streams must share a geometry (%s vs %s)" % (fr.geometry(), fq.geometry()))
+    if want_c:
+        lo, hi = series["range"]
+        idx = selected_indices(n, complexity.interval)
+    else:
+        lo = hi = 0
+
     # ---- chunks: (a, b) dense source range (quality present) or (j0, j1) sample range (complexity only)
-    per_frame = fb * (2 if want_q else 1)
-    host = src.kind != "device"
-    staged = host and (src.kind == "pageable" or (want_q and rsrc.kind == "pageable"))
+    interval = complexity.interval if want_c else None
+    per_frame = 0  # host bytes a source frame brings along
+    if want_q:
+        per_frame += sum(feeds[k].fb for k in (("ref", "qdist") if split else ("ref", "dist")) if feeds[k].host)
+        if split and want_c and feeds["dist"].host:
+            per_frame += -(-feeds["dist"].fb // interval)
+    elif feeds["dist"].host:
+        per_frame = feeds["dist"].fb
+    host = any(f.host for f in feeds.values())
+    staged = any(f.staged for f in feeds.values())
     limit = STAGED_CHUNK_BYTES_MAX if staged else CHUNK_BYTES_MAX
     cap = max(1, min(int(batch_size), limit // max(per_frame, 1) if host else int(batch_size)))
-    nchunks = -(-n // cap) if want_q else -(-(hi - lo) // cap)
+    plans = plan_chunks(n, want_q, interval, lo, hi, cap, split)
+    nchunks = len(plans)
     # ---- lanes
     farneback = want_c and (complexity.mask & N.M_MOTION) and complexity.motion_mode == N.MOTION_FARNEBACK
     if engine is not None or nchunks <= 1 or farneback or MAX_LANES < 2:
@@ -361,106 +474,124 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
     st = _staging_of(first) if host else None
     params = first.make_params(resize=complexity.resize, dct_mode=complexity.dct_mode,
                                motion_mode=complexity.motion_mode) if want_c else None
-    if host:
-        for ln in range(len(lanes)):  # lane buffers: slot 0 of the distorted stream is the halo (the frame before the chunk's first sample)
-            st.device_buffer(ln, "dist", (cap + 1) * fb)
-            if want_q:
-                st.device_buffer(ln, "ref", cap * fb)
-    ring = st.ring(len(lanes) + 1, (cap + 1) * fb + (cap * fb if want_q else 0)) if staged else None
+    # ---- buffers: every host feed gets a buffer per lane (slot 0 of the complexity stream is the halo, the frame before the
+    # chunk's first sample), every staged feed a region of each ring slot
+    off = 0
+    for f in feeds.values():
+        f.slots = max([slot + cnt for p in plans for slot, _s, cnt, _t in p.get(f.key, ())] or [0])
+        if f.host and f.slots:
+            for ln in range(len(lanes)):
+                st.device_buffer(ln, f.name, f.slots * f.fb)
+        if f.staged:
+            f.ring_off = off
+            off += f.slots * f.fb
+    ring = st.ring(len(lanes) + 1, off) if staged else None
     free_slots = list(range(len(ring))) if staged else None
-
-    plans = plan_chunks(n, want_q, complexity.interval if want_c else None, lo if want_c else 0, hi if want_c else 0, cap)
+    fills = []  # every copier future of the pass that may still be running
 
     def plan(k):
         """chunk k's plan with its host copies as views of the sources"""
         p = dict(plans[k])
-        p["copies"] = [_Copy(slot, src.view(start, count, step)) for slot, start, count, step in p["copies"]] if host else []
-        p["rcopies"] = [_Copy(slot, rsrc.view(start, count, step)) for slot, start, count, step in p["rcopies"]] if host else []
+        for f in feeds.values():
+            p[f.key] = [_Copy(slot, f.src.view(start, cnt, step)) for slot, start, cnt, step in p.get(f.key, ())] if f.host else []
         return p
 
     def start_fill(p):
         if not staged:
             return
-        slot = free_slots.pop()
-        blk = ring[slot]
-        p["slot"] = slot
-        p["ring_d"] = blk[:(cap + 1) * fb].reshape(cap + 1, fb)
-        futs = _fill_slot(st.copiers(), p["ring_d"], p["copies"])
-        if want_q:
-            p["ring_r"] = blk[(cap + 1) * fb:(cap + 1) * fb + cap * fb].reshape(cap, fb)
-            futs += _fill_slot(st.copiers(), p["ring_r"], p["rcopies"])
-        p["fill"] = futs
+        with N.trace_range("vqa:gather chunk=%d", p["k"]):
+            slot = free_slots.pop()
+            blk = ring[slot]
+            p["slot"], p["ring"], futs = slot, {}, []
+            for f in feeds.values():
+                if f.staged and f.slots:
+                    region = blk[f.ring_off:f.ring_off + f.slots * f.fb].reshape(f.slots, f.fb)
+                    p["ring"][f.name] = region
+                    futs += _fill_slot(st.copiers(), region, p[f.key])
+            p["fill"] = futs
+            fills.extend(futs)
 
     def submit(p, eng):
-        if host:
-            for f in p.get("fill", ()):
-                f.result()
-            ln = p["k"] % len(lanes)
-            dd = st.device_buffer(ln, "dist", (cap + 1) * fb)
-            _upload(eng, dd.ptr, fb, p["copies"], p.get("ring_d"))
-            if want_q:
-                dr = st.device_buffer(ln, "ref", cap * fb)
-                _upload(eng, dr.ptr, fb, p["rcopies"], p.get("ring_r"))
+        ln = p["k"] % len(lanes)
+        if p.get("fill"):
+            with N.trace_range("vqa:gather-wait chunk=%d lane=%d", p["k"], ln):
+                for f in p["fill"]:
+                    f.result()
+                fills[:] = [f for f in fills if not f.done()]
+        dev = {}
+        with N.trace_range("vqa:upload chunk=%d lane=%d", p["k"], ln):
+            for f in feeds.values():
+                if f.host and f.slots and p[f.key]:
+                    dev[f.name] = st.device_buffer(ln, f.name, f.slots * f.fb)
+                    _upload(eng, dev[f.name].ptr, f.fb, p[f.key], p.get("ring", {}).get(f.name))
         p["has_q"] = p["has_c"] = False
-        if want_q:
-            if host:
-                qr = DeviceFrames(dr.ptr, p["qn"], 1, fb, frame_stride=fb, row_stride=fb, owner=dr, channels=1)
-                qd = DeviceFrames(dd.ptr + fb, p["qn"], 1, fb, frame_stride=fb, row_stride=fb, owner=dd, channels=1)
-            else:
-                qr, qd = ref.slice(p["q0"], p["q0"] + p["qn"]), dist.slice(p["q0"], p["q0"] + p["qn"])
-            eng.quality_submit(qr, qd, quality.planes, quality.ssim_mode)
-            p["has_q"] = True
-        if want_c and p["j1"] > p["j0"]:
-            m = p["j1"] - p["j0"]
-            if host:
-                h, w = dist.shape[1], dist.shape[2]
-                batch = DeviceFrames(dd.ptr + (1 + p["first"]) * fb, m, h, w, frame_stride=fb * p["step"], owner=dd)
-                prev0 = DeviceFrames(dd.ptr + (1 + p["prev_slot"]) * fb, 1, h, w, owner=dd)
-            else:
-                # every frame_interval-th frame, zero-copy: the batch is a strided view of the resident clip
-                s0 = int(idx[1 + p["j0"]])
-                batch = DeviceFrames(dist.ptr + s0 * dist.frame_stride, m, dist.h, dist.w,
-                                     frame_stride=dist.frame_stride * complexity.interval, row_stride=dist.row_stride,
-                                     owner=dist, channels=dist.channels)
-                prev0 = dist.frame(int(idx[p["j0"]]))
-            eng.complexity_submit(batch, prev0, complexity.mask, params)
-            p["has_c"] = True
+        with N.trace_range("vqa:submit chunk=%d lane=%d", p["k"], ln):
+            if want_q:
+                fq, fr = feeds["qdist" if split else "dist"], feeds["ref"]
+                pair = []
+                for f, slot0 in ((fr, 0), (fq, p["qslot"])):
+                    if f.host:
+                        b = dev[f.name]
+                        pair.append(DeviceFrames(b.ptr + slot0 * f.fb, p["qn"], 1, f.fb, frame_stride=f.fb, row_stride=f.fb,
+                                                 owner=b, channels=1))
+                    else:
+                        pair.append(f.src.frames.slice(p["q0"], p["q0"] + p["qn"]))
+                eng.quality_submit(pair[0], pair[1], quality.planes, quality.ssim_mode)
+                p["has_q"] = True
+            if want_c and p["j1"] > p["j0"]:
+                m = p["j1"] - p["j0"]
+                fd = feeds["dist"]
+                if fd.host:
+                    h, w = dist.shape[1], dist.shape[2]
+                    dd, fb = dev["dist"], fd.fb
+                    batch = DeviceFrames(dd.ptr + (1 + p["first"]) * fb, m, h, w, frame_stride=fb * p["step"], owner=dd)
+                    prev0 = DeviceFrames(dd.ptr + (1 + p["prev_slot"]) * fb, 1, h, w, owner=dd)
+                else:
+                    # every frame_interval-th frame, zero-copy: the batch is a strided view of the resident clip
+                    s0 = int(idx[1 + p["j0"]])
+                    batch = DeviceFrames(dist.ptr + s0 * dist.frame_stride, m, dist.h, dist.w,
+                                         frame_stride=dist.frame_stride * complexity.interval, row_stride=dist.row_stride,
+                                         owner=dist, channels=dist.channels)
+                    prev0 = dist.frame(int(idx[p["j0"]]))
+                eng.complexity_submit(batch, prev0, complexity.mask, params)
+                p["has_c"] = True
 
     sse, ssim = [], []
     arrays = {k: [] for k in KINDS + ("temporal",)}  # the same series as float64 arrays, for the pooling (no list round trip)
 
     def wait(p, eng):
         """block until the chunk is done on its lane; its records are kept, its ring slot is free again"""
-        if p["has_q"]:
-            p["qres"] = eng.quality_wait()
-        if p["has_c"]:
-            p["rec"] = eng.complexity_wait()
+        with N.trace_range("vqa:wait chunk=%d lane=%d", p["k"], p["k"] % len(lanes)):
+            if p["has_q"]:
+                p["qres"] = eng.quality_wait()
+            if p["has_c"]:
+                p["rec"] = eng.complexity_wait()
         if staged:
             free_slots.append(p["slot"])  # every copy out of the slot has completed
 
     def finish(p):
         """the host work of a finished chunk: float tails and stats lines (runs AFTER the lane has its next chunk)"""
-        if p["has_q"]:
-            res = p.pop("qres")
-            sse.append(res["sse"])
-            ssim.append(res["ssim"])
-            if on_quality is not None:
-                on_quality(p["q0"], sse[-1], ssim[-1])
-        if p["has_c"]:
-            rec = p.pop("rec")
-            for kind in KINDS:
-                if complexity.mask & MASK[kind]:
-                    v = tails.values(kind, rec, complexity.motion_mode)
-                    series[kind].extend(tails.as_list(kind, v))
-                    arrays[kind].append(v)
-            if complexity.mask & N.M_TEMPORAL_DCT:
-                # the reference's first pair only primes prev_gray_frame (:533-537)
-                v = tails.values("temporal", rec)[1 if p["j0"] == 0 else 0:]
-                series["temporal"].extend(tails.as_list("temporal", v))
-                arrays["temporal"].append(v)
+        with N.trace_range("vqa:tails chunk=%d", p["k"]):
+            if p["has_q"]:
+                res = p.pop("qres")
+                sse.append(res["sse"])
+                ssim.append(res["ssim"])
+                if on_quality is not None:
+                    on_quality(p["q0"], sse[-1], ssim[-1])
+            if p["has_c"]:
+                rec = p.pop("rec")
+                for kind in KINDS:
+                    if complexity.mask & MASK[kind]:
+                        v = tails.values(kind, rec, complexity.motion_mode)
+                        series[kind].extend(tails.as_list(kind, v))
+                        arrays[kind].append(v)
+                if complexity.mask & N.M_TEMPORAL_DCT:
+                    # the reference's first pair only primes prev_gray_frame (:533-537)
+                    v = tails.values("temporal", rec)[1 if p["j0"] == 0 else 0:]
+                    series["temporal"].extend(tails.as_list("temporal", v))
+                    arrays["temporal"].append(v)
 
     pending = []
-    nxt = None
     try:
         nxt = plan(0)
         start_fill(nxt)
@@ -482,10 +613,10 @@ def run(dist, ref=None, quality=None, complexity=None, batch_size=100, engine=No
             wait(p, eng)
             finish(p)
     except BaseException:
-        for f in (nxt or {}).get("fill", ()):  # a copier may still be writing into the ring: the next pass must not meet it
+        for f in fills:  # a copier may still be writing into the ring: the next pass (or ring()'s free) must not meet it
             try:
                 f.result()
-            except Exception:
+            except BaseException:
                 pass
         _abandon(lanes)
         raise

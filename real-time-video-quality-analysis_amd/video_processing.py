@@ -9,9 +9,9 @@ instead of container files: decode is out of scope.  VMAF is out of scope: no
 vmaf log is written, and — as in the reference when the file is absent (:169) —
 the 'VMAF' key is simply missing.
 """
-import math
 import os
 import re
+import threading
 
 import numpy as np
 
@@ -52,7 +52,7 @@ def _host_stream(a):
 
 
 def frame_quality(reference, distorted, layout="bgr24", ssim_mode="gauss", height=None, width=None, engine=None,
-                  batch_size=64, on_chunk=None):
+                  batch_size=64, on_chunk=None, device=None):
     """Per-frame SSE and SSIM per plane.  Returns (sse [n,p] uint64, ssim [n,p] float64, plane sizes).
     One pass (stream.run): chunks of up to batch_size frame pairs alternate between two engines; host streams travel
     from the caller's pinned memory or through the pinned ring.  on_chunk(first_frame, sse, ssim) sees every finished
@@ -63,7 +63,7 @@ def frame_quality(reference, distorted, layout="bgr24", ssim_mode="gauss", heigh
     h, w = _geometry(reference, layout, height, width)
     planes = LAYOUTS[layout][0](h, w)
     q, _ = stream.run(distorted, reference, quality=stream.Quality(planes, _SSIM_MODES[ssim_mode]),
-                      batch_size=batch_size, engine=engine, on_quality=on_chunk)
+                      batch_size=batch_size, engine=engine, on_quality=on_chunk, device=device)
     return q[0], q[1], [(p[0], p[1]) for p in planes]
 
 
@@ -151,11 +151,13 @@ def _open_quality_stream(src, layout, height, width):
         return arr, "yuv420p", h, w
     if layout == "bgr24":
         return _open_frames(src), layout, height, width
+    if isinstance(src, str):
+        raise ValueError("Unsupported file type. Please provide a .y4m (yuv420p) or .npy ([N,H,W,3] BGR) stream.")
     return src, layout, height, width
 
 
 def run_ffmpeg_metrics(reference_video, distorted_video, psnr_log, ssim_log, vmaf_log, vmaf_model_path=None,
-                       layout="bgr24", ssim_mode="gauss", height=None, width=None, batch_size=64):
+                       layout="bgr24", ssim_mode="gauss", height=None, width=None, batch_size=64, device=None):
     """video_processing.py:270-297 — PSNR and SSIM between two streams, one stats line per frame.
     Streams: [N,H,W,3] BGR arrays / .npy (components r,g,b as FFmpeg labels RGB input), planar yuv420p
     arrays with height/width, or .y4m files (components y,u,v — what FFmpeg sees for an H.264 clip)."""
@@ -166,23 +168,21 @@ def run_ffmpeg_metrics(reference_video, distorted_video, psnr_log, ssim_log, vma
     h, w = _geometry(ref, layout, height, width)
     wr = _StatsWriter(psnr_log, ssim_log, layout, [(p[0], p[1]) for p in LAYOUTS[layout][0](h, w)])
     try:
-        frame_quality(ref, dist, layout, ssim_mode, height, width, batch_size=batch_size, on_chunk=wr)
+        frame_quality(ref, dist, layout, ssim_mode, height, width, batch_size=batch_size, on_chunk=wr, device=device)
     finally:
         wr.close()
     return None
 
 
+_csv_lock = threading.Lock()
+
+
 def thread_safe_update_csv(metrics, csv_file="video_quality_data.csv"):
-    """video_processing.py:44-68 — append one row, header only when the file is new (no pandas needed)."""
+    """video_processing.py:44-68 — append one row, header only when the file is new (no pandas needed).  The "is the file
+    new" test sits INSIDE the lock (the reference tests at :56 before taking it at :62, so two threads can both write a header)."""
     import csv
-    import threading
-    global _csv_lock
-    try:
-        _csv_lock
-    except NameError:
-        _csv_lock = threading.Lock()
-    exists = os.path.isfile(csv_file)
     with _csv_lock:
+        exists = os.path.isfile(csv_file) and os.path.getsize(csv_file) > 0
         with open(csv_file, "a", newline="") as f:
             wr = csv.writer(f)
             if not exists:
@@ -190,43 +190,99 @@ def thread_safe_update_csv(metrics, csv_file="video_quality_data.csv"):
             wr.writerow(list(metrics.values()))
 
 
+# the keys this build adds to the reference's config.json (config.json:1-7 keeps its five; SURVEY.md section 5 "Config / flag system")
+MODE_KEYS = {
+    # key: (allowed values, message in the reference's validate_config style)
+    "ssim_mode": (("gauss", "ffmpeg"), "ssim_mode must be 'gauss' or 'ffmpeg'."),
+    "pixfmt": ((None, "bgr24", "yuv420p", "gray"), "pixfmt must be 'bgr24', 'yuv420p' or 'gray'."),
+    "dct_mode": ((None, "auto", "block8", "full"), "dct_mode must be 'auto', 'block8' or 'full'."),
+    "motion": ((None, "sad", "farneback"), "motion must be 'sad' or 'farneback'."),
+}
+
+
+def _check_mode_keys(config):
+    for key, (allowed, message) in MODE_KEYS.items():
+        if key in config and config[key] not in allowed:
+            raise ValueError(message)
+    dev = config.get("device")
+    if dev is not None and (isinstance(dev, bool) or not isinstance(dev, int) or dev < 0):
+        raise ValueError("device must be a non-negative integer.")
+    bs = config.get("batch_size", 100)
+    if isinstance(bs, bool) or not isinstance(bs, int) or bs <= 0:
+        raise ValueError("batch_size must be a positive integer.")
+
+
 def process_video_and_extract_metrics(input_video, encoded_video, config, csv_file="video_quality_data.csv",
-                                      bitrate=0, frame_rate=30.0, column_order="reference"):
+                                      bitrate=0, frame_rate=30.0, column_order="reference", encoded_bgr=None,
+                                      height=None, width=None):
     """video_processing.py:180-267 minus the libx264 encode and ffprobe steps (external codec, out of
     scope): both streams arrive decoded.  Quality metrics compare input vs encoded (:216); complexity is
-    computed on the ENCODED stream (:242-243).  column_order="reference" keeps the reference's unpacking of
-    the 8-tuple (:235-242), which shifts five labels; "fixed" uses the tuple's true order."""
+    computed on the ENCODED stream (:242-247).  ONE pass (stream.run) serves both.
+
+    input_video / encoded_video   the pair the quality filters compare:
+        [N,H,W,3] BGR frames (.npy, array, torch tensor, DeviceFrames) - the complexity kernels then read the same
+            encoded frames, every chunk is uploaded once; or
+        the decoded planes FFmpeg's psnr / ssim filters see (:274-276): .y4m files or planar [N, H*W*3/2] yuv420p
+            arrays (config pixfmt "yuv420p") - together with
+    encoded_bgr                   the encoded stream as cv2.VideoCapture decodes it ([N,H,W,3] BGR: .npy, array, tensor,
+        DeviceFrames; complexity_metrics.py:100), which the complexity half reads.  Per chunk the planar pair and the chunk's
+        selected BGR frames are uploaded, each byte once.
+    config   the reference's keys (crf, resize_width, resize_height, frame_interval, vmaf_model_path; config.json:1-7) plus
+        batch_size, ssim_mode ("gauss" north_star's 11x11 Gaussian, default | "ffmpeg" vf_ssim's 8x8 integer windows),
+        pixfmt (None: by input | "bgr24" | "yuv420p" | "gray"), dct_mode ("auto" default: full-frame up to 128x128, 8x8 blocks
+        above | "block8" | "full" the reference's cv2.dct at any size), motion ("sad" north_star's block-SAD | "farneback" the
+        reference's own; default: set_motion_mode / VQA_MOTION) and device (GPU index; default VQA_DEVICE, LOCAL_RANK, 0).
+    column_order="reference" keeps the reference's unpacking of the 8-tuple (:235-242), which shifts five labels
+    (SURVEY.md §3.2); "fixed" uses the tuple's true order."""
     import tempfile
     import uuid
     from . import complexity_metrics as cm
+    _check_mode_keys(config)
     crf = config.get("crf", 23)
     rw, rh = config.get("resize_width", 64), config.get("resize_height", 64)
     interval = config.get("frame_interval", 10)
+    batch_size = config.get("batch_size", 100)
+    ssim_mode = _SSIM_MODES[config.get("ssim_mode", "gauss")]
+    dct_mode = cm._DCT_MODES[config.get("dct_mode")]
+    motion_mode = cm.motion_mode_of(config.get("motion"))
+    device = config.get("device")
+    layout = config.get("pixfmt") or "bgr24"
     uid = uuid.uuid4().hex
     tmp = tempfile.gettempdir()
     psnr_log, ssim_log, vmaf_log = (os.path.join(tmp, "%s_%s.log" % (k, uid)) for k in ("psnr", "ssim", "vmaf"))
-    batch_size = config.get("batch_size", 100)
     try:
-        y4m = any(isinstance(v, str) and v.endswith(".y4m") for v in (input_video, encoded_video))
-        if y4m:
-            # planar quality inputs and a BGR complexity input are different bytes: two passes
-            run_ffmpeg_metrics(input_video, encoded_video, psnr_log, ssim_log, vmaf_log, config.get("vmaf_model_path"))
-            enc = _open_frames(encoded_video)
-            series = cm.complexity_series(enc, rw, rh, interval, batch_size)
+        ref, layout, qh, qw = _open_quality_stream(input_video, layout, height, width)
+        qenc, layout_d, _h, _w = _open_quality_stream(encoded_video, layout, qh, qw)
+        if layout_d != layout:
+            raise ValueError("reference and distorted streams must share a pixel layout")
+        if layout == "bgr24" and encoded_bgr is None:
+            enc, qdist = qenc, None       # (:216 and :242 read the same encoded stream: every chunk is uploaded once)
         else:
-            # ONE pass (:216 and :242 read the same encoded stream): every chunk is uploaded once, the quality kernels
-            # read all of its frames and the complexity kernels every interval-th of them
-            ref, enc = _open_frames(input_video), _open_frames(encoded_video)
-            h, w = _geometry(enc, "bgr24", None, None)
-            planes = bgr_planes(h, w)
-            wr = _StatsWriter(psnr_log, ssim_log, "bgr24", [(p[0], p[1]) for p in planes])
-            try:
-                _q, series = stream.run(enc, ref, quality=stream.Quality(planes, N.SSIM_GAUSS),
-                                        complexity=stream.Complexity((rw, rh), interval, motion_mode=cm._motion_mode),
-                                        batch_size=batch_size, on_quality=wr)
-            finally:
-                wr.close()
-        resolution = "%dx%d" % (enc.shape[2], enc.shape[1]) if hasattr(enc, "shape") else "%dx%d" % (enc.w, enc.h)
+            if encoded_bgr is None:
+                raise ValueError("a %s quality pair needs the encoded stream's BGR frames for the complexity half "
+                                 "(complexity_metrics.py:100 reads cv2's BGR decode): pass encoded_bgr=" % layout)
+            enc, qdist = _open_frames(encoded_bgr), _host_stream(qenc)
+            ref = _host_stream(ref)
+        eh, ew = (enc.h, enc.w) if isinstance(enc, DeviceFrames) else (enc.shape[1], enc.shape[2])
+        if qdist is None:
+            h, w = eh, ew
+        else:
+            h, w = _geometry(ref, layout, qh or eh, qw or ew)
+            if layout == "yuv420p":
+                from .frames import frame_bytes_yuv420p
+                for a in (ref, qdist):
+                    if not isinstance(a, DeviceFrames) and (a.ndim != 2 or a.shape[1] != frame_bytes_yuv420p(h, w)):
+                        raise ValueError("yuv420p streams must be planar [N, H*W*3/2] uint8 arrays of the frames' geometry "
+                                         "(%dx%d: %d bytes per frame)" % (w, h, frame_bytes_yuv420p(h, w)))
+        planes = LAYOUTS[layout][0](h, w)
+        wr = _StatsWriter(psnr_log, ssim_log, layout, [(p[0], p[1]) for p in planes])
+        try:
+            _q, series = stream.run(enc, ref, quality=stream.Quality(planes, ssim_mode),
+                                    complexity=stream.Complexity((rw, rh), interval, dct_mode=dct_mode, motion_mode=motion_mode),
+                                    batch_size=batch_size, on_quality=wr, qdist=qdist, device=device)
+        finally:
+            wr.close()
+        resolution = "%dx%d" % (ew, eh)
         metrics = extract_metrics_from_logs(psnr_log, ssim_log, vmaf_log, input_video, crf, bitrate, resolution, frame_rate)
         t = cm.pool_series(series, enc, interval, batch_size=batch_size, fps=frame_rate)
         if column_order == "reference":   # (:235-242) motion, dct, temporal, hist, edge, orb, colour, fps
@@ -272,7 +328,7 @@ def load_config(config_file):
 
 
 def validate_config(config):
-    """video_processing.py:87-98 — same range checks, same messages."""
+    """video_processing.py:87-98 — same range checks, same messages; then this build's added keys in the same style."""
     if not (1 <= config.get("crf", 23) <= 51):
         raise ValueError("CRF value must be between 1 and 51.")
     if config.get("resize_width", 0) <= 0 or config.get("resize_height", 0) <= 0:
@@ -281,6 +337,7 @@ def validate_config(config):
         raise ValueError("Frame interval must be a positive integer.")
     if not isinstance(config.get("num_workers", (os.cpu_count() or 2) // 2), int):
         raise ValueError("num_workers must be an integer.")
+    _check_mode_keys(config)  # this build's keys: ssim_mode, pixfmt, dct_mode, motion, device, batch_size
 
 
 def main(argv=None):
@@ -290,12 +347,13 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description="Quality + complexity metrics of an (input, encoded) stream pair -> CSV row.")
     ap.add_argument("config_file")
     ap.add_argument("input_video", help="reference stream: .npy [N,H,W,3] BGR")
-    ap.add_argument("encoded_video", help="distorted stream, same geometry")
+    ap.add_argument("encoded_video", help="distorted stream, same geometry (.npy BGR, or .y4m with --encoded-bgr)")
+    ap.add_argument("--encoded-bgr", default=None, help="with a .y4m quality pair: the encoded stream's BGR frames (.npy) for the complexity half")
     ap.add_argument("--csv", default="video_quality_data.csv")
     ap.add_argument("--column-order", default="reference", choices=["reference", "fixed"])
     a = ap.parse_args(argv)
     m = process_video_and_extract_metrics(a.input_video, a.encoded_video, load_config(a.config_file), csv_file=a.csv,
-                                          column_order=a.column_order)
+                                          column_order=a.column_order, encoded_bgr=a.encoded_bgr)
     print(m)
     return 0
 

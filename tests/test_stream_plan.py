@@ -60,3 +60,38 @@ def test_quality_only_passes_have_no_samples():
     plans = stream.plan_chunks(25, True, None, 0, 0, 10)
     assert [(p["q0"], p["qn"]) for p in plans] == [(0, 10), (10, 10), (20, 5)]
     assert all(p["j0"] == p["j1"] for p in plans)
+
+
+def test_split_passes_move_every_byte_of_either_stream_once():
+    """split = the quality pair (planar planes, dense) and the encoded BGR stream (the chunk's selected frames, compact) are
+    different bytes: the quality copies cover 0..n-1 once, the BGR copies are exactly the samples' frames plus one previous
+    frame per chunk that has samples, and the samples are the reference's (:103-104, :268-290)."""
+    for n, interval, cap in itertools.product((0, 1, 2, 9, 10, 11, 30, 31, 64, 101), (1, 2, 3, 7, 10), (1, 3, 8, 100)):
+        sel = [t for t in range(n) if (t + 1) % interval == 0]
+        want = [(sel[j + 1], sel[j]) for j in range(len(sel) - 1)]
+        qframes, samples, moved, chunks_with_samples = [], [], 0, 0
+        for p in stream.plan_chunks(n, True, interval, 0, len(want), cap, split=True):
+            assert p["qslot"] == 0 and p["rcopies"] == p["qcopies"] == [(0, p["q0"], p["qn"], 1)]
+            qframes.extend(range(p["q0"], p["q0"] + p["qn"]))
+            m = p["j1"] - p["j0"]
+            if not m:
+                assert p["copies"] == []
+                continue
+            chunks_with_samples += 1
+            buf = np.full(m + 1, -1)
+            for slot, start, count, step in p["copies"]:
+                assert 0 <= slot and slot + count <= m + 1
+                buf[slot:slot + count] = np.arange(start, start + (count - 1) * step + 1, step)
+                moved += count
+            assert (buf >= 0).all() and buf.max() < n
+            for i in range(m):
+                f = buf[1 + p["first"] + i * p["step"]]
+                prev = buf[1 + p["prev_slot"]] if i == 0 else buf[1 + p["first"] + (i - 1) * p["step"]]
+                samples.append((int(f), int(prev)))
+                assert q0_le(p, f)      # a sample's frame lies in the chunk's own source range
+        assert qframes == list(range(n)) and samples == want, (n, interval, cap)
+        assert moved == len(want) + chunks_with_samples
+
+
+def q0_le(p, f):
+    return p["q0"] <= f < p["q0"] + p["qn"]
