@@ -92,7 +92,7 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < fb; i++) enc[fb * t + i] = (uint8_t)(r[i] + 1);
     }
     int pinned = -1;
-    CHECK(vqa_host_is_pinned(ctx[0], ref, &pinned));
+    CHECK(vqa_host_is_pinned(ctx[0], ref, fb * (size_t)n, &pinned));
     if (pinned != 0) { fprintf(stderr, "malloc'ed memory reported as pinned\n"); return 1; }
 
     /* the pinned ring (slot = halo frame + chunk of encoded frames, then the chunk of reference frames) and the lanes'
@@ -101,7 +101,7 @@ int main(int argc, char **argv)
     const size_t enc_bytes = fb * (size_t)(chunk + 1), slot_bytes = enc_bytes + fb * (size_t)chunk;
     for (int s = 0; s < SLOTS; s++) CHECK(vqa_alloc_pinned(ctx[0], slot_bytes, (void **)&ring[s]));
     for (int l = 0; l < LANES; l++) CHECK(vqa_alloc_device(ctx[l], slot_bytes, (void **)&dev[l]));
-    CHECK(vqa_host_is_pinned(ctx[0], ring[0], &pinned));
+    CHECK(vqa_host_is_pinned(ctx[0], ring[0], slot_bytes, &pinned));
     if (pinned != 1) { fprintf(stderr, "the ring is not page-locked\n"); return 1; }
 
     vqa_params p;

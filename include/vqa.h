@@ -63,7 +63,7 @@ extern "C" {
 #define VQA_API
 #endif
 
-#define VQA_ABI_VERSION 6
+#define VQA_ABI_VERSION 7
 #define VQA_TABLE_CACHE_GEOMETRIES 16
 
 typedef enum vqa_status {
@@ -73,7 +73,9 @@ typedef enum vqa_status {
     VQA_ERR_HIP = -3,         /* a HIP runtime call failed (vqa_last_hip_error)         */
     VQA_ERR_OOM = -4,         /* device or pinned allocation failed                     */
     VQA_ERR_UNSUPPORTED = -5, /* valid request this build does not implement            */
-    VQA_ERR_STATE = -6        /* wait without submit, submit while one is pending ...   */
+    VQA_ERR_STATE = -6,       /* wait without submit, submit while one is pending ...   */
+    VQA_ERR_INCOMPLETE = -7   /* a result would be inexact and is withheld: vqa_complexity_wait when a frame's Canny
+                                 hysteresis did not reach its fixpoint (vqa_last_hip_error names the frame)            */
 } vqa_status;
 
 typedef struct vqa_ctx vqa_ctx;
@@ -144,8 +146,11 @@ typedef struct vqa_frame_metrics {
                                     0 unless VQA_OPT_HYST_STATS is set on the ctx (it costs an atomic per visit) */
     uint32_t orb_keypoints;      /* len(ORB_create().detectAndCompute(gray64)[0])  (:385-389)  */
     uint32_t orb_response;       /* FAST score of that keypoint, 0 when there is none       */
-    uint32_t hyst_overflow;      /* 1 if the Canny hysteresis hit its round bound before the fixpoint:
-                                    edge_count is then a LOWER bound, not the exact count (never seen; asserted 0 in tests) */
+    uint32_t hyst_overflow;      /* how the Canny hysteresis of this frame ended.  0: the tail reached the fixpoint (every frame
+                                    seen so far).  2: the tail stopped at its round bound and the rescue pass completed the
+                                    fixpoint on the device - edge_count is exact either way.  1 is never returned: a frame that
+                                    neither pass finished makes vqa_complexity_wait fail with VQA_ERR_INCOMPLETE and zero the
+                                    records - edge_count is a bit-exact count or there is no count (complexity_metrics.py:503-504) */
     double   flow_mag_mean;      /* VQA_MOTION_FARNEBACK: np.mean(|flow|) (:342-343); else 0.  Bar: 1e-4 relative against
                                     the CPU restatement of cv2.calcOpticalFlowFarneback, EXCEPT on frames where a border
                                     pixel's flow lies within float rounding of FarnebackUpdateMatrices' in-frame test
@@ -209,10 +214,11 @@ VQA_API int vqa_get_option(const vqa_ctx *ctx, int option, int *value);
 /* ---- memory --------------------------------------------------------------- */
 VQA_API int vqa_alloc_pinned(vqa_ctx *ctx, size_t bytes, void **out);
 VQA_API int vqa_free_pinned(vqa_ctx *ctx, void *p);
-/* *out = 1 if p points into page-locked host memory HIP knows (vqa_alloc_pinned, hipHostMalloc, hipHostRegister, a
- * torch tensor with pin_memory=True): a *_submit / vqa_copy_h2d from it is a true asynchronous DMA.  0 for ordinary
- * (pageable) host memory - the host side then stages through pinned buffers of its own - and for device memory.       */
-VQA_API int vqa_host_is_pinned(vqa_ctx *ctx, const void *p, int *out);
+/* *out = 1 if the WHOLE range [p, p + bytes) is page-locked host memory HIP knows (vqa_alloc_pinned, hipHostMalloc,
+ * hipHostRegister, a torch tensor with pin_memory=True; first and last byte are probed): a *_submit / vqa_copy_h2d from it is
+ * a true asynchronous DMA.  0 for ordinary (pageable) host memory - the host side then stages through pinned buffers of
+ * its own - for a range that leaves a registered region, and for device memory.                                          */
+VQA_API int vqa_host_is_pinned(vqa_ctx *ctx, const void *p, size_t bytes, int *out);
 VQA_API int vqa_alloc_device(vqa_ctx *ctx, size_t bytes, void **out);
 VQA_API int vqa_free_device(vqa_ctx *ctx, void *p);
 /* async on the ctx stream; host side should be pinned for true overlap */

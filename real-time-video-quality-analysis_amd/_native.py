@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB_PATH") or os.path.join(_HERE, "csrc", "libvqa_hip.so")
 LAB_LIB_PATH = os.path.join(_HERE, "csrc", "lab", "libvqa_hip_lab.so")
 
-VQA_ABI_VERSION = 6
+VQA_ABI_VERSION = 7
 VQA_TABLE_CACHE_GEOMETRIES = 16
 
 VQA_OK = 0
@@ -22,6 +22,7 @@ VQA_ERR_HIP = -3
 VQA_ERR_OOM = -4
 VQA_ERR_UNSUPPORTED = -5
 VQA_ERR_STATE = -6
+VQA_ERR_INCOMPLETE = -7
 
 VQA_MEM_HOST = 0
 VQA_MEM_DEVICE = 1
@@ -96,7 +97,7 @@ SIGNATURES = {
     "vqa_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "vqa_alloc_pinned": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vqa_free_pinned": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "vqa_host_is_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "vqa_host_is_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "vqa_alloc_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vqa_free_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vqa_copy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -173,7 +174,7 @@ def load():
 def check(status, where, ctx=None):
     if status != VQA_OK:
         detail = ""
-        if ctx is not None and status in (VQA_ERR_HIP, VQA_ERR_OOM):
+        if ctx is not None and status in (VQA_ERR_HIP, VQA_ERR_OOM, VQA_ERR_INCOMPLETE):
             detail = load().vqa_last_hip_error(ctx).decode()
         raise VqaError(status, where, detail)
 

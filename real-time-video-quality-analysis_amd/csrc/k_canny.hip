@@ -868,15 +868,62 @@ __global__ __launch_bounds__(256) void k_canny_hyst_list(hyst_args A, const unsi
 // fence + workgroup barrier: the promotions a round stored are released to L2 and this CU's L1 is
 // invalidated before the next round loads them (every producer and consumer of a frame's tiles is in
 // this one workgroup, so nothing outside it needs to see the flag traffic).  The loop is bounded.
+//
+// rescue = 0: the tail proper.  It stops at max_rounds (CANNY_HYST_MAX_ROUNDS; a drain bound, far above what frames need)
+//   and then SAYS so: res[f].hyst_overflow = 1 - the edge plane is a subset of the fixpoint, the count a lower bound.
+// rescue = 1: launched right after the tail, same stream.  A frame whose flag is clear leaves at once (one load per
+//   workgroup).  A flagged frame is finished here: the aborted run's lists are forgotten, round 0 relaxes EVERY tile of
+//   the frame (relaxation is monotone and idempotent, so starting over from the current planes is exact), then the list
+//   rounds run to the fixpoint under the bound the algorithm itself gives: a list is non-empty only because the round
+//   before it promoted a weak pixel, and a pixel is promoted once, so there are at most edge_weak + 1 non-empty rounds.
+//   On success the flag becomes 2 ("completed by the rescue pass": edge_count is exact).  A flag still 1 at
+//   vqa_complexity_wait means the bound of the proof was hit - a defect, not a frame - and the wait fails
+//   (VQA_ERR_INCOMPLETE): a lower bound is never returned as a count.
+__device__ __forceinline__ void hyst_round_handoff()
+{
+    // (guide G16) every storing wave drains its stores, the workgroup meets, ONE lane releases to L2 and then
+    // invalidates this CU's L1, the workgroup meets again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(1024) void k_canny_hyst_tail(hyst_args A, unsigned *__restrict__ list0,
                                                          unsigned *__restrict__ cnt0, unsigned *__restrict__ q0,
                                                          unsigned *__restrict__ list1, unsigned *__restrict__ cnt1,
-                                                         unsigned *__restrict__ q1, int first_in, int max_rounds)
+                                                         unsigned *__restrict__ q1, int first_in, int max_rounds, int rescue)
 {
     __shared__ unsigned s_cnt[HSEG];
+    __shared__ unsigned s_flag, s_weak;
     const unsigned f = blockIdx.x, tpf = (unsigned)(A.tiles_y * A.ww);
     unsigned *lists[2] = {list0, list1}, *cnts[2] = {cnt0, cnt1}, *qs[2] = {q0, q1};
     int in = first_in;
+    if (rescue) {
+        if (threadIdx.x == 0) { s_flag = A.res[f].hyst_overflow; s_weak = A.res[f].edge_weak; }
+        __syncthreads();
+        if (s_flag != 1u) return; // (workgroup-uniform) the tail reached this frame's fixpoint: nothing to do
+        // forget the aborted run: both dedup flag sets of the frame's tiles and both append counters
+        for (unsigned t = threadIdx.x; t < tpf; t += blockDim.x) { q0[f * tpf + t] = 0; q1[f * tpf + t] = 0; }
+        if (threadIdx.x < HSEG) { cnt0[f * HSEG + threadIdx.x] = 0; cnt1[f * HSEG + threadIdx.x] = 0; }
+        hyst_round_handoff();
+        // round 0: every tile of the frame, wakes into list 1
+        A.queued = qs[1];
+        A.out_list = lists[1];
+        A.out_count = cnts[1];
+        for (unsigned g = wave_id(); g < tpf; g += blockDim.x / 64) relax_tile(A, f * tpf + g);
+        hyst_round_handoff();
+        in = 1;
+        if (max_rounds <= 0) { // the proof's bound (see above), clamped to an int
+            const unsigned wk = s_weak;
+            max_rounds = wk > 0x7ffffff0u ? 0x7ffffff2 : (int)wk + 2;
+        }
+    }
     bool reached_fixpoint = false;
     for (int round = 0; round < max_rounds; round++) {
         if (threadIdx.x < HSEG) {
@@ -899,18 +946,22 @@ __global__ __launch_bounds__(1024) void k_canny_hyst_tail(hyst_args A, unsigned 
             if (lane_id() == 0) qs[in][tile] = 0;
             relax_tile(A, tile);
         }
-        // hand-off to the next round (guide G16): every storing wave drains its stores, the workgroup
-        // meets, ONE lane releases to L2 and then invalidates this CU's L1, the workgroup meets again.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
+        hyst_round_handoff(); // hand-off to the next round
         in ^= 1;
+    }
+    if (rescue) {
+        // (a bound that ends the loop exactly after the last non-empty round leaves an empty list behind: that IS the fixpoint)
+        if (!reached_fixpoint) {
+            __syncthreads(); // (s_cnt is rewritten: every wave has left the loop's reads)
+            if (threadIdx.x < HSEG) s_cnt[threadIdx.x] = cnts[in][f * HSEG + threadIdx.x];
+            __syncthreads();
+            unsigned n = 0;
+#pragma unroll
+            for (int k = 0; k < HSEG; k++) n += s_cnt[k];
+            reached_fixpoint = n == 0;
+        }
+        if (reached_fixpoint && threadIdx.x == 0) A.res[f].hyst_overflow = 2u; // completed here: the count is exact
+        return;
     }
     // the bound exists so the grid always drains; hitting it leaves an UNDER-count, which the record must say
     if (!reached_fixpoint && threadIdx.x < HSEG && cnts[in][f * HSEG + threadIdx.x] != 0) A.res[f].hyst_overflow = 1u;
@@ -1002,16 +1053,19 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
 }
 
 // rounds 2.. to convergence, one workgroup per frame, no host involvement.  lists/counts/queued: the two
-// per-frame work lists; first_in = index of the list the first tail round consumes.
+// per-frame work lists; first_in = index of the list the first tail round consumes.  Two launches: the tail, then the
+// rescue pass (k_canny_hyst_tail, rescue = 1), which costs one load per frame unless the tail stopped at its bound.
+// max_rounds / rescue_max_rounds: 0 = the shipped bounds (lab seams pass small ones to force either outcome).
 void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *list0, unsigned *cnt0, unsigned *q0, unsigned *list1, unsigned *cnt1,
-                            unsigned *q1, int first_in, vqa_frame_metrics *res, int stats, int max_rounds)
+                            unsigned *q1, int first_in, vqa_frame_metrics *res, int stats, int max_rounds, int rescue_max_rounds)
 {
     if (n <= 0) return;
     if (max_rounds <= 0) max_rounds = CANNY_HYST_MAX_ROUNDS;
-    hipLaunchKernelGGL(k_canny_hyst_tail, dim3(n), dim3(1024), 0, st,
-                       make_hyst_args(strong, weak, h, w, nullptr, nullptr, nullptr, res, stats), list0, cnt0, q0, list1, cnt1,
-                       q1, first_in, max_rounds);
+    const hyst_args A = make_hyst_args(strong, weak, h, w, nullptr, nullptr, nullptr, res, stats);
+    hipLaunchKernelGGL(k_canny_hyst_tail, dim3(n), dim3(1024), 0, st, A, list0, cnt0, q0, list1, cnt1, q1, first_in, max_rounds, 0);
+    hipLaunchKernelGGL(k_canny_hyst_tail, dim3(n), dim3(1024), 0, st, A, list0, cnt0, q0, list1, cnt1, q1, first_in,
+                       rescue_max_rounds > 0 ? rescue_max_rounds : 0, 1);
 }
 
 void launch_canny_finish(hipStream_t st, const unsigned long long *strong, int n, int h, int w, vqa_frame_metrics *res)

@@ -52,6 +52,7 @@ struct vqa_ctx {
     bool opt_overlap = true, opt_hyst_stats = false;
     // -DVQA_TEST_SEAMS only (lab build; read from the environment once, in vqa_create)
     int seam_hyst_max_rounds = 0;   // VQA_HYST_MAX_ROUNDS: the hysteresis tail's round bound (0 = the shipped bound)
+    int seam_hyst_rescue_max_rounds = 0; // VQA_HYST_RESCUE_MAX_ROUNDS: the rescue pass's bound (0 = the proof's: edge_weak + 2)
     long seam_fail_at = 0;          // VQA_FAIL_ENSURE_AT=N: the N-th scratch reservation of this ctx reports VQA_ERR_OOM
     long seam_ensure_calls = 0;
     long long seam_fb_chunk_bytes = 0; // VQA_FB_CHUNK_BYTES: Farneback's scratch budget per chunk (0 = the shipped 12 GiB): lets a small batch span chunks
@@ -708,6 +709,7 @@ const char *vqa_strerror(int s)
     case VQA_ERR_OOM: return "out of memory";
     case VQA_ERR_UNSUPPORTED: return "unsupported request";
     case VQA_ERR_STATE: return "call sequence error";
+    case VQA_ERR_INCOMPLETE: return "a result would be inexact and is withheld";
     default: return "unknown status";
     }
 }
@@ -750,6 +752,7 @@ int vqa_create(int device, vqa_ctx **out)
     if (const char *e = getenv("VQA_OVERLAP")) c->opt_overlap = atoi(e) != 0;
 #ifdef VQA_TEST_SEAMS
     if (const char *e = getenv("VQA_HYST_MAX_ROUNDS")) c->seam_hyst_max_rounds = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = getenv("VQA_HYST_RESCUE_MAX_ROUNDS")) c->seam_hyst_rescue_max_rounds = atoi(e) > 0 ? atoi(e) : 0;
     if (const char *e = getenv("VQA_FAIL_ENSURE_AT")) c->seam_fail_at = atol(e);
     if (const char *e = getenv("VQA_FB_CHUNK_BYTES")) c->seam_fb_chunk_bytes = atoll(e);
 #endif
@@ -858,17 +861,22 @@ int vqa_free_pinned(vqa_ctx *c, void *p)
     HIPCHK(c, hipHostFree(p));
     return VQA_OK;
 }
-int vqa_host_is_pinned(vqa_ctx *c, const void *p, int *out)
+static bool host_byte_is_pinned(const void *p)
 {
-    if (!c || !p || !out) return VQA_ERR_INVALID;
-    *out = 0;
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof a);
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { // ordinary host memory: HIP has never heard of it
         (void)hipGetLastError();
-        return VQA_OK;
+        return false;
     }
-    *out = a.type == hipMemoryTypeHost ? 1 : 0;
+    return a.type == hipMemoryTypeHost;
+}
+int vqa_host_is_pinned(vqa_ctx *c, const void *p, size_t bytes, int *out)
+{
+    if (!c || !p || !out || !bytes) return VQA_ERR_INVALID;
+    // the first AND the last byte: an array that starts inside a registered region and ends outside it (hipHostRegister
+    // of part of a buffer) is pageable as far as a DMA of the whole range is concerned
+    *out = (host_byte_is_pinned(p) && host_byte_is_pinned((const uint8_t *)p + (bytes - 1))) ? 1 : 0;
     return VQA_OK;
 }
 int vqa_alloc_device(vqa_ctx *c, size_t bytes, void **out)
@@ -1205,7 +1213,7 @@ static int complexity_submit_body(vqa_ctx *c, const uint8_t *frames, const uint8
             tc[round & 1] = cnt(round);
             tc[(round & 1) ^ 1] = cnt(round + 1);
             launch_canny_hyst_tail(st_canny, strong, weak, n, ph, pw, lists[0], tc[0], queued[0], lists[1], tc[1], queued[1],
-                                   round & 1, res, c->opt_hyst_stats, c->seam_hyst_max_rounds);
+                                   round & 1, res, c->opt_hyst_stats, c->seam_hyst_max_rounds, c->seam_hyst_rescue_max_rounds);
         }
         launch_canny_finish(st_canny, strong, n, ph, pw, res);
         c->last_has_state = true;
@@ -1272,6 +1280,16 @@ int vqa_complexity_wait(vqa_ctx *c, vqa_frame_metrics *out, int n)
         out[i].has_prev = (i > 0 || c->pend_c_prev0) ? 1u : 0u;
     }
     c->pend_c = 0;
+    // north_star: edge counts are bit-exact.  A frame whose hysteresis neither the tail nor the rescue pass brought to
+    // the fixpoint (hyst_overflow still 1) has a LOWER BOUND in edge_count: that is never handed out as a count.
+    for (int i = 0; i < n; i++)
+        if (out[i].hyst_overflow == 1u) {
+            c->last_err = "Canny hysteresis of frame " + std::to_string(i) + " of " + std::to_string(n) +
+                          " stopped before its fixpoint (edge_count " + std::to_string(out[i].edge_count) +
+                          " would be a lower bound): records withheld";
+            memset(out, 0, sizeof(vqa_frame_metrics) * (size_t)n);
+            return VQA_ERR_INCOMPLETE;
+        }
     return VQA_OK;
 }
 

@@ -10,7 +10,7 @@
 //   -DVQA_AB_VARIANTS  (make lab) additionally compiles the superseded kernels of earlier rounds and their VQA_*_VARIANT /
 //                      tuning selectors, for re-measurement (LAB_NOTES.md); results stay parity-tested.
 //   -DVQA_TEST_SEAMS   (make lab) additionally compiles the fault-injection / stand-in hooks the tests use:
-//                      VQA_COMM_FAKE_RCCL, VQA_HYST_MAX_ROUNDS, VQA_FAIL_ENSURE_AT, VQA_FB_CHUNK_BYTES.
+//                      VQA_COMM_FAKE_RCCL, VQA_HYST_MAX_ROUNDS, VQA_HYST_RESCUE_MAX_ROUNDS, VQA_FAIL_ENSURE_AT, VQA_FB_CHUNK_BYTES.
 #ifdef VQA_AB_VARIANTS
 #include <cstdlib>
 #endif
@@ -98,8 +98,9 @@ void launch_canny_hyst_list(hipStream_t st, unsigned long long *strong, const un
                             vqa_frame_metrics *res, int stats);
 void launch_canny_hyst_tail(hipStream_t st, unsigned long long *strong, const unsigned long long *weak, int n, int h,
                             int w, unsigned *list0, unsigned *cnt0, unsigned *q0, unsigned *list1, unsigned *cnt1,
-                            unsigned *q1, int first_in, vqa_frame_metrics *res, int stats, int max_rounds);
-constexpr int CANNY_HYST_MAX_ROUNDS = 1 << 16; // the tail's drain bound (a 64x64-tile fixpoint over any frame ends far below)
+                            unsigned *q1, int first_in, vqa_frame_metrics *res, int stats, int max_rounds, int rescue_max_rounds);
+constexpr int CANNY_HYST_MAX_ROUNDS = 1 << 16; // the tail's drain bound (a 64x64-tile fixpoint over any frame ends far below); a frame
+                                               // that hits it is finished by the rescue pass under the proof's bound (k_canny.hip)
 void launch_canny_finish(hipStream_t st, const unsigned long long *strong, int n, int h, int w, vqa_frame_metrics *res);
 
 // k_sad.hip

@@ -156,12 +156,16 @@ class Engine:
             N.check(self.lib.vqa_free_pinned(self.ctx, p), "vqa_free_pinned", self.ctx)
 
     def is_pinned(self, arr):
-        """True if the array's memory is page-locked and known to HIP (alloc_pinned, torch pin_memory, hipHostRegister):
-        a submit / h2d from it is an asynchronous DMA; pageable memory is staged through a pinned ring (stream.py)."""
+        """True if the array's memory - ALL of it, first byte to last - is page-locked and known to HIP (alloc_pinned, torch
+        pin_memory, hipHostRegister): a submit / h2d from it is an asynchronous DMA; pageable memory, and an array that
+        only starts inside a registered region, is staged through a pinned ring (stream.py)."""
         if getattr(arr, "nbytes", 0) == 0:
             return False
+        if any(st < 0 for st in arr.strides):
+            return False
+        span = sum((n - 1) * st for n, st in zip(arr.shape, arr.strides)) + arr.itemsize  # first byte .. last byte of a strided view
         out = C.c_int(0)
-        N.check(self.lib.vqa_host_is_pinned(self.ctx, arr.ctypes.data, C.byref(out)), "vqa_host_is_pinned", self.ctx)
+        N.check(self.lib.vqa_host_is_pinned(self.ctx, arr.ctypes.data, span, C.byref(out)), "vqa_host_is_pinned", self.ctx)
         return bool(out.value)
 
     def h2d_async(self, dst_ptr, src_ptr, nbytes):

@@ -51,7 +51,7 @@ def _no_hysteresis_overflow(engine, monkeypatch):
 
     def checked():
         rec = wait()
-        assert not rec["hyst_overflow"].any(), "Canny hysteresis stopped at its round bound"
+        assert not rec["hyst_overflow"].any(), "Canny hysteresis stopped at its round bound (2 = the rescue pass had to finish it)"
         return rec
     monkeypatch.setattr(engine, "complexity_wait", checked)
 
@@ -953,39 +953,68 @@ def test_half_built_tables_are_freed_and_rebuilt(fail_at):
     assert r.returncode == 0 and "DRAIN-OK 1" in r.stdout, (fail_at, r.stdout[-300:], r.stderr[-1500:])
 
 
-def test_hysteresis_overflow_is_flagged():
-    """The tail's round bound exists so the grid always drains; hitting it must SAY so (hyst_overflow = 1) instead of
-    returning a silent under-count.  Forced here with the LAB build's VQA_HYST_MAX_ROUNDS=1 seam (subprocess); the
-    shipped library has no such switch and must report the full count."""
+_HYST_CODE = (
+    "import json, os, sys, numpy as np; sys.path.insert(0, %r)\n"
+    "import rtvqa_amd\n"
+    "from rtvqa_amd import _native as N\n"
+    "from oracle import c_oracle as co\n"
+    "r = np.full((80, 4000), 20, np.uint8); r[40, :] = 50; r[40, 5] = 255\n"      # a weak line 62 tiles long, one strong seed
+    "rng = np.random.default_rng(5); noise = rng.integers(0, 256, (80, 4000), dtype=np.uint8)\n"
+    "fr = np.repeat(np.stack([noise, r, noise[::-1].copy()])[..., None], 3, 3)\n"
+    "want = [int(co.canny(g, 100, 200)[0]) for g in (noise, r, noise[::-1].copy())]\n"
+    "eng = rtvqa_amd.Engine(0)\n"
+    "try:\n"
+    "    rec = eng.complexity(fr, mask=N.M_EDGE)\n"
+    "    print('RESULT', json.dumps([[int(v) for v in rec['hyst_overflow']], [int(v) for v in rec['edge_count']], want]))\n"
+    "except N.VqaError as e:\n"
+    "    print('REFUSED', e.status, str(e))\n"
+    "    for k in ('VQA_HYST_MAX_ROUNDS', 'VQA_HYST_RESCUE_MAX_ROUNDS'): os.environ.pop(k, None)\n"
+    "    rec = eng.complexity(fr[:1], mask=N.M_EDGE)\n"                             # the refusing context stays usable ...
+    "    e2 = rtvqa_amd.Engine(0)\n"                                                # ... and a context without the seams finishes the batch
+    "    rec2 = e2.complexity(fr, mask=N.M_EDGE)\n"
+    "    print('AFTER', int(rec[0]['edge_count']) == want[0], [int(v) for v in rec2['hyst_overflow']], [int(v) for v in rec2['edge_count']] == want)\n"
+)
+
+
+def test_hysteresis_overflow_is_completed_or_refused_never_undercounted():
+    """north_star: edge counts are bit-exact.  The tail's round bound exists so the grid always drains; a frame that hits it is
+    finished ON THE DEVICE by the rescue pass (hyst_overflow = 2, edge_count exact = the oracle's), and if even that stops
+    short vqa_complexity_wait FAILS (VQA_ERR_INCOMPLETE, records zeroed) - a lower bound is never returned as a count.
+    Both forced with the LAB build's seams (VQA_HYST_MAX_ROUNDS, VQA_HYST_RESCUE_MAX_ROUNDS; subprocesses); the shipped
+    library has no such switches and must report the full count with the flag clear."""
     import subprocess
     import sys
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "import rtvqa_amd\n"
-        "from rtvqa_amd import _native as N\n"
-        "r = np.full((80, 4000), 20, np.uint8); r[40, :] = 50; r[40, 5] = 255\n"
-        "fr = np.repeat(r[None, :, :, None], 3, 3)\n"
-        "eng = rtvqa_amd.Engine(0)\n"
-        "rec = eng.complexity(fr, mask=N.M_EDGE)\n"
-        "print('RESULT', int(rec[0]['hyst_overflow']), int(rec[0]['edge_count']))\n" % REPO_ROOT
-    )
     from rtvqa_amd import _native as N
-    out = {}
-    for rounds in ("1", "", "shipped"):
-        env = dict(os.environ, VQA_LIB_PATH=N.LAB_LIB_PATH)
-        env.pop("VQA_HYST_MAX_ROUNDS", None)
-        if rounds == "shipped":  # the variable is set, the shipped library must ignore it
-            env.pop("VQA_LIB_PATH")
-            env["VQA_HYST_MAX_ROUNDS"] = "1"
-        elif rounds:
-            env["VQA_HYST_MAX_ROUNDS"] = rounds
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+
+    def run(lab, **seams):
+        env = dict(os.environ)
+        for k in ("VQA_HYST_MAX_ROUNDS", "VQA_HYST_RESCUE_MAX_ROUNDS", "VQA_LIB_PATH"):
+            env.pop(k, None)
+        if lab:
+            env["VQA_LIB_PATH"] = N.LAB_LIB_PATH
+        env.update(seams)
+        r = subprocess.run([sys.executable, "-c", _HYST_CODE % REPO_ROOT], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-800:]
-        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
-        out[rounds] = (int(line[1]), int(line[2]))
-    assert out[""][0] == 0 and out["1"][0] == 1, out
-    assert out["shipped"] == out[""], out
-    assert out["1"][1] < out[""][1], out  # the bounded run is an under-count, and says so
+        return [l for l in r.stdout.splitlines() if l.startswith(("RESULT", "REFUSED", "AFTER"))]
+
+    import json
+    plain = run(True)
+    assert len(plain) == 1 and plain[0].startswith("RESULT "), plain
+    flags, got, want = json.loads(plain[0][len("RESULT "):])
+    assert flags == [0, 0, 0] and got == want and got[1] > 3900, plain     # (the whole weak line is an edge)
+    # the tail stops after ONE round: the 62-tile chain is nowhere near done - the rescue pass finishes it, and says so
+    rescued = run(True, VQA_HYST_MAX_ROUNDS="1")
+    assert len(rescued) == 1 and rescued[0].startswith("RESULT "), rescued
+    flags2, got2, want2 = json.loads(rescued[0][len("RESULT "):])
+    assert got2 == want2 == want and flags2[1] == 2 and set(flags2) <= {0, 2}, rescued
+    # both passes bounded: no count at all, an error that names the frame, and the context stays usable
+    refused = run(True, VQA_HYST_MAX_ROUNDS="1", VQA_HYST_RESCUE_MAX_ROUNDS="1")
+    assert len(refused) == 2 and refused[0].startswith("REFUSED %d " % N.VQA_ERR_INCOMPLETE), refused
+    assert "frame 1 of 3" in refused[0] and "lower bound" in refused[0], refused
+    assert refused[1] == "AFTER True [0, 0, 0] True", refused
+    # the shipped library ignores the variables
+    shipped = run(False, VQA_HYST_MAX_ROUNDS="1", VQA_HYST_RESCUE_MAX_ROUNDS="1")
+    assert shipped == plain, (shipped, plain)
 
 
 def test_results_are_bit_identical_run_to_run(engine):

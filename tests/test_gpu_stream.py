@@ -280,3 +280,29 @@ def test_ssim_depends_on_the_batch_size_only_in_the_last_digits():
     b2 = vp.frame_quality(ref, dist, batch_size=3)
     assert np.array_equal(a[0], b[0]) and np.array_equal(b[0], b2[0]) and np.array_equal(b[1], b2[1])
     assert np.max(np.abs(a[1] - b[1]) / a[1]) <= 1e-8
+
+
+def test_a_clip_that_only_starts_in_registered_memory_is_not_dma_ed_from():
+    """vqa_host_is_pinned probes the first AND the last byte: a clip whose head lies in a hipHostRegister'ed region and whose
+    tail does not is pageable as far as a whole-range DMA is concerned - it goes through the ring and gives the same bits."""
+    import torch
+    from rtvqa_amd import complexity_metrics as cm
+    n, h, w = 12, 72, 96
+    clip = _clip(n, h, w, seed=77)
+    page = 4096
+    raw = np.zeros(clip.nbytes + 2 * page, np.uint8)
+    off = (-raw.ctypes.data) % page
+    buf = raw[off:off + clip.nbytes].reshape(clip.shape)
+    buf[...] = clip
+    half = (clip.nbytes // 2) // page * page
+    eng = cm.get_engine()
+    rt = torch.cuda.cudart()
+    assert int(rt.cudaHostRegister(buf.ctypes.data, half, 0)) == 0
+    try:
+        head = buf.reshape(-1)[:half]
+        assert eng.is_pinned(head) and eng.is_pinned(head[100:200])
+        assert not eng.is_pinned(buf) and not eng.is_pinned(buf.reshape(-1)[half - 10:half + 10])
+        assert not eng.is_pinned(buf[::-1])
+        _same_series(cm.complexity_series(buf, 64, 48, 2, batch_size=4), cm.complexity_series(clip, 64, 48, 2, batch_size=4))
+    finally:
+        assert int(rt.cudaHostUnregister(buf.ctypes.data)) == 0
