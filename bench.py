@@ -207,7 +207,7 @@ def cpu_baseline(h, w, full, sample, motion="sad", verify_items=()):
                        "cores//2 = %d of the %d cores visible to the process), chunksize 1, batch_size 100"
                        % (sample, workers, cores))
     line.update(second_cpu_figure(workers, override, lambda wk, m: _timed_pool(_cpu_item, items[:m], wk), sample))
-    return expect, line
+    return expect, finish_cpu_line(line)
 
 
 def _timed_pool(fn, items, workers):
@@ -221,8 +221,8 @@ def _timed_pool(fn, items, workers):
 
 def second_cpu_figure(workers, override, run, sample):
     """The reference sizes its pool from os.cpu_count() and never looks at the container's CPU quota: on a box whose cgroup
-    allows fewer cores than it shows, `value` above is what the reference's rule gives (oversubscribed).  Beside it, NOT
-    instead of it: the same items with one worker per core the cgroup really grants, on half the sample."""
+    allows fewer cores than it shows, its rule oversubscribes.  The same items with one worker per core the cgroup really
+    grants, on half the sample - finish_cpu_line() then reports the FASTER of the two as `value`."""
     lim = cgroup_cpu_limit()
     if override or not lim or workers <= lim:
         return {}
@@ -231,6 +231,27 @@ def second_cpu_figure(workers, override, run, sample):
     dt = run(wk, m)
     return {"at_cgroup_limit": dict(value=round(m / dt, 3), workers=wk, seconds=round(dt, 2),
                                     sample="%d of the same items, one worker per core the cgroup grants" % m)}
+
+
+def finish_cpu_line(line):
+    """`value` is the honest CPU figure: the faster of (the reference's rule: cores // 2 workers of the cores the process SEES)
+    and (one worker per core the cgroup GRANTS).  `cores` = the cores that actually ran it: min(workers, cgroup limit).  The
+    other figure stays beside it (reference_rule / at_cgroup_limit), so a ratio taken from `value` is never inflated by
+    an oversubscribed pool (128 workers on a 16-core cgroup ran 1.7x slower than 16)."""
+    lim = line.get("cgroup_cpu_limit")
+    alt = line.get("at_cgroup_limit")
+    line["cores"] = int(min(line["workers"], lim)) if lim else line["workers"]
+    if alt and alt["value"] > line["value"]:
+        line["reference_rule"] = dict(value=line["value"], workers=line["workers"], seconds=line["seconds"],
+                                      what="ProcessPoolExecutor(max_workers = visible cores // 2), as complexity_metrics.py:264-265 "
+                                           "sizes it: oversubscribes a cgroup that grants fewer cores than it shows")
+        line.update(value=alt["value"], seconds=alt["seconds"], workers=alt["workers"], cores=alt["workers"],
+                    value_is="at_cgroup_limit (the faster of the two pool sizes)")
+        line["sample"] = line["sample"] + "; `value`: " + alt["sample"]
+        del line["at_cgroup_limit"]
+    else:
+        line["value_is"] = "reference_rule (cores // 2 workers)"
+    return line
 
 
 # ---------------------------------------------------------------------------
@@ -608,7 +629,7 @@ def cpu_baseline_c1(ref, dist):
         c1_oracle(ref[:m], dist[:m], wk)
         return time.perf_counter() - t1
     line.update(second_cpu_figure(workers, override, again, min(sample, 200)))
-    return (sample, tup, q), line
+    return (sample, tup, q), finish_cpu_line(line)
 
 
 def main_c1(args, rank, local_rank, world):
@@ -628,11 +649,12 @@ def main_c1(args, rank, local_rank, world):
         nv = min(n, 30)
         expect = (nv,) + c1_oracle(ref_h[:nv], dist_h[:nv], 1, pool=False)
 
+    rehearsal = "VQA_BENCH_DEVICE" in os.environ
+    device = int(os.environ.get("VQA_BENCH_DEVICE", local_rank))
+    affinity = bind_numa(device, args.bind_numa)  # after the CPU baseline (it used every visible core), before any GPU call
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    rehearsal = "VQA_BENCH_DEVICE" in os.environ
-    device = int(os.environ.get("VQA_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(device)
     os.environ["VQA_DEVICE"] = str(device)  # the entry points' default engine (stream.get_engine)
     dist_on = world > 1 or args.dist_always
@@ -761,7 +783,7 @@ def main_c1(args, rank, local_rank, world):
                            "backend": backend_used, "rccl_ranks": rccl_ranks, "devices": devices, "resident": "HBM",
                            "ssim_mode": "gauss", "pixfmt": "bgr24", "dct_mode": "auto (full-frame at 64x64, as cv2.dct)",
                            "motion": "sad", "parallelism": "1 clip/GPU x%d" % world, "lanes": stream.MAX_LANES,
-                           "overlap": bool(args.overlap)},
+                           "overlap": bool(args.overlap), "cpu_affinity": affinity},
                 "roofline": roof, "kernels": kernels,
                 "serial": {"ms_per_step": round(dt_serial / args.steps * 1e3, 4), "fps": round(n * args.steps / dt_serial, 1),
                            "what": "the same pass (stream.run) on ONE context, VQA_OPT_OVERLAP off, HIP-event profiling on"} if dt_serial else None,
@@ -791,6 +813,82 @@ def main_c1(args, rank, local_rank, world):
     cm.release_buffers()
     if c1_bad:
         os._exit(4)
+
+
+# ---------------------------------------------------------------------------
+# N > 1 without a launcher: `python bench.py --gpus N` starts the N ranks itself, as fresh children, and relays.
+# ---------------------------------------------------------------------------
+def launch_ranks(n):
+    """No WORLD_SIZE in the environment and --gpus N > 1: this process has touched no GPU (nothing above imports torch.cuda or
+    loads the library), so it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>` as a
+    CHILD process (never an exec: a restart of a process is not what a GPU box allows), lets rank 0's JSON line through on
+    the inherited stdout and returns the launcher's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] --gpus %d without a launcher: starting %d ranks: %s\n" % (n, n, " ".join(cmd)))
+    sys.stderr.flush()
+    env = dict(os.environ, VQA_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")   # (what torchrun would set with a warning)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_local_cpus(index, sysfs="/sys"):
+    """The CPUs local to HIP device `index` (its NUMA node), from sysfs alone - no GPU call: KFD topology nodes in node order
+    are the HIP devices in device order; each names its PCI function (domain, location_id = bus << 8 | devfn), whose
+    local_cpulist is the answer.  -> (set of cpus, source path) or (None, reason)."""
+    vis = next((os.environ[k] for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(k)), None)
+    if vis is not None:
+        try:
+            index = [int(x) for x in vis.split(",")][index]
+        except (ValueError, IndexError):
+            return None, "device visibility list %r is not a plain index list" % vis
+    nodes_dir = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        gpus = []
+        for node in sorted(os.listdir(nodes_dir), key=int):
+            props = dict(line.split()[:2] for line in open(os.path.join(nodes_dir, node, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        pr = gpus[index]
+        loc, dom = int(pr["location_id"]), int(pr.get("domain", "0"))
+        path = os.path.join(sysfs, "bus", "pci", "devices", "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7),
+                            "local_cpulist")
+        cpus = _parse_cpulist(open(path).read())
+        return (cpus, path) if cpus else (None, "empty " + path)
+    except (OSError, ValueError, KeyError, IndexError) as e:
+        return None, "sysfs: %s" % e
+
+
+def bind_numa(device, enabled=True, sysfs="/sys"):
+    """--bind-numa: pin this rank (and the copier threads it will start) to the CPUs of its GPU's NUMA node BEFORE any GPU
+    call.  With eight ranks feeding eight GPUs over PCIe, a copier thread on the far socket halves its bandwidth.
+    -> the record for config.cpu_affinity."""
+    if not enabled:
+        return {"bound": False, "why": "--no-bind-numa"}
+    if not hasattr(os, "sched_setaffinity"):
+        return {"bound": False, "why": "no sched_setaffinity on this platform"}
+    cpus, src = gpu_local_cpus(device, sysfs)
+    if cpus is None:
+        return {"bound": False, "why": src}
+    have = os.sched_getaffinity(0)
+    want = cpus & have
+    if not want:
+        return {"bound": False, "why": "the GPU's local CPUs %s are outside this process's affinity" % sorted(cpus)[:4]}
+    if want != have:
+        os.sched_setaffinity(0, want)
+    return {"bound": True, "cpus": len(want), "of_visible": len(have), "first": min(want), "last": max(want), "source": src}
 
 
 # ---------------------------------------------------------------------------
@@ -837,14 +935,23 @@ def main():
                     help="skip the post-timing check of the last timed step's records against the oracle")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the rank logic)")
+    ap.add_argument("--no-bind-numa", dest="bind_numa", action="store_false",
+                    help="do not pin the rank to the CPUs of its GPU's NUMA node (default: pinned before any GPU call when "
+                         "sysfs tells which CPUs those are; recorded as config.cpu_affinity)")
     ap.add_argument("--stub-engine", action="store_true",
                     help="CPU rehearsal of the N > 1 rank logic under gloo: no kernels run, the line carries \"stub\": true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks as fresh children, relay, never touch a GPU here (an 8-GPU run that came back
+        # with "n_gpus": 1 and rc 0 was the failure mode of round 5)
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.stub_engine and args.backend != "gloo":
         raise SystemExit("--stub-engine is a CPU rehearsal: use --backend gloo")
@@ -880,9 +987,11 @@ def main():
     elif world == 1 and rank == 0 and args.cpu_sample != 0 and not stub:
         _, cpu_line = cpu_baseline(h, w, full, args.cpu_sample, args.motion)
 
-    import torch
     rehearsal = "VQA_BENCH_DEVICE" in os.environ
     device = int(os.environ.get("VQA_BENCH_DEVICE", local_rank))
+    # after the CPU baseline (it used every visible core), before any GPU call
+    affinity = bind_numa(device, args.bind_numa) if not stub else {"bound": False, "why": "--stub-engine: no GPU to be near"}
+    import torch
     if not stub:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
@@ -1113,7 +1222,9 @@ def main():
                   "backend": backend_used, "rccl_ranks": rccl_ranks, "devices": devices, "rehearsal_single_device": bool(rehearsal and world > 1),
                   "resident": "HBM", "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode,
                   "motion": args.motion, "parallelism": "1 stream/GPU x%d" % world,
-                  "overlap": bool(args.overlap)}
+                  "overlap": bool(args.overlap), "cpu_affinity": affinity,
+                  "launched_by": "bench.py itself (--gpus N without a launcher)" if os.environ.get("VQA_BENCH_LAUNCHED") else
+                                 ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct")}
         if stub:
             line.update({"data": "STUB: no kernels ran (rank-logic rehearsal, --stub-engine)", "stub": True, "config": config,
                          "roofline": None, "kernels": {}})

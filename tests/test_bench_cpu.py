@@ -183,3 +183,89 @@ def test_c1_is_a_workload_and_refuses_the_stub():
     assert bench.WORKLOADS["c1"]["batch"] == 300 and bench.C1_CONFIG["frame_interval"] == 10 and bench.C1_CONFIG["resize_width"] == 64
     r = _run([sys.executable, "bench.py", "--workload", "c1", "--stub-engine", "--backend", "gloo"])
     assert r.returncode != 0 and "c1 has no stub" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gpus_n_without_a_launcher_starts_n_ranks(world):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: the parent touches no GPU, starts the N ranks as
+    fresh torch.distributed.run children and relays rank 0's ONE line and the exit code - round 5's bench printed
+    "n_gpus": 1 with rc 0 here, which would have made the first 8-GPU record a 1-GPU measurement."""
+    env = {k: None for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e = dict(os.environ)
+    for k in env:
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--backend", "gloo", "--stub-engine"],
+                       cwd=REPO, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly ONE JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["config"]["devices"] == list(range(world))
+    assert line["config"]["launched_by"].startswith("bench.py itself") and "starting %d ranks" % world in r.stderr
+    frames = line["config"]["frames_per_step_per_gpu"] * line["steps"] * world
+    assert abs(line["value"] - frames / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-3 * line["value"]
+
+
+def test_launcherless_run_relays_a_failing_rank():
+    """the launcher's exit code is the bench's: a rank that refuses its arguments fails the whole run, and no line is printed"""
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--stub-engine"], cwd=REPO, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # a WORLD_SIZE that disagrees with --gpus stays fatal, also for WORLD_SIZE=1 (one rank started through a launcher)
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--stub-engine", "--backend", "gloo"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def _fake_sysfs(tmp_path, gpus):
+    """a sysfs with one CPU node and `gpus` = [(domain, bus, dev, fn, cpulist)] KFD GPU nodes"""
+    nodes = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for k, (dom, bus, dev, fn, cpus) in enumerate(gpus, 1):
+        (nodes / str(k)).mkdir()
+        (nodes / str(k) / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain %d\n" % ((bus << 8) | (dev << 3) | fn, dom))
+        d = tmp_path / "bus" / "pci" / "devices" / ("%04x:%02x:%02x.%x" % (dom, bus, dev, fn))
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text(cpus + "\n")
+    return str(tmp_path)
+
+
+def test_bind_numa_reads_the_gpus_cpus_from_sysfs_and_binds_before_any_gpu_call(tmp_path, monkeypatch):
+    for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    have = sorted(os.sched_getaffinity(0))
+    lo = "%d-%d" % (have[0], have[len(have) // 2]) if len(have) > 1 else str(have[0])
+    sysfs = _fake_sysfs(tmp_path, [(0, 0x05, 0, 0, lo), (0, 0x85, 0, 0, "4000-4003"), (1, 0xc5, 0, 0, "%d,%d" % (have[0], have[-1]))])
+    assert bench._parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    cpus, src = bench.gpu_local_cpus(0, sysfs)
+    assert cpus == bench._parse_cpulist(lo) and src.endswith("0000:05:00.0/local_cpulist")
+    assert bench.gpu_local_cpus(2, sysfs)[0] == {have[0], have[-1]}
+    assert bench.gpu_local_cpus(5, sysfs)[0] is None                      # no such GPU: not an error, no binding
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert bench.gpu_local_cpus(0, sysfs)[0] == {have[0], have[-1]}      # device 0 of this process is the node's GPU 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef")
+    assert bench.gpu_local_cpus(0, sysfs)[0] is None
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    try:
+        rec = bench.bind_numa(0, True, sysfs)
+        assert rec["bound"] and rec["cpus"] == len(bench._parse_cpulist(lo) & set(have)) and os.sched_getaffinity(0) == bench._parse_cpulist(lo) & set(have)
+        assert bench.bind_numa(1, True, sysfs)["bound"] is False          # the GPU's CPUs are not ours (another cpuset): left alone
+        assert bench.bind_numa(0, False, sysfs) == {"bound": False, "why": "--no-bind-numa"}
+        assert bench.bind_numa(0, True, str(tmp_path / "nowhere"))["bound"] is False
+    finally:
+        os.sched_setaffinity(0, have)
+
+
+def test_cpu_baseline_value_is_the_honest_figure():
+    """ADVICE round 5: `value` was the oversubscribed pool (128 workers on a 16-core cgroup, 1.7x slower than 16 workers);
+    now the faster of the two pool sizes is `value`, `cores` = the cores that ran it, and the other figure stays beside it."""
+    over = dict(value=18.1, workers=128, seconds=10.0, cgroup_cpu_limit=16.0, sample="s",
+                at_cgroup_limit=dict(value=30.8, workers=16, seconds=5.0, sample="half"))
+    line = bench.finish_cpu_line(dict(over))
+    assert line["value"] == 30.8 and line["cores"] == 16 and line["workers"] == 16 and line["value_is"].startswith("at_cgroup_limit")
+    assert line["reference_rule"]["value"] == 18.1 and line["reference_rule"]["workers"] == 128 and "at_cgroup_limit" not in line
+    same = bench.finish_cpu_line(dict(value=40.0, workers=8, seconds=3.0, cgroup_cpu_limit=None, sample="s"))
+    assert same["value"] == 40.0 and same["cores"] == 8 and same["value_is"].startswith("reference_rule")
+    slow = bench.finish_cpu_line(dict(value=40.0, workers=32, seconds=3.0, cgroup_cpu_limit=16.0, sample="s",
+                                      at_cgroup_limit=dict(value=35.0, workers=16, seconds=2.0, sample="half")))
+    assert slow["value"] == 40.0 and slow["cores"] == 16 and slow["at_cgroup_limit"]["value"] == 35.0
