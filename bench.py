@@ -4,6 +4,8 @@
   python bench.py --gpus 1 --steps K --warmup W                  (N = 1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W   (N > 1, one rank per GPU)
+  python bench.py --gpus N ...                                   (N > 1 with no launcher: bench.py starts that very
+         torch.distributed.run command itself as a child process, relays rank 0's line and the exit code)
 
 A "step" is one pass of the selected workload over one device-resident batch of
 frames.  `value` is timed on the product's own configuration: block-SAD and the
@@ -25,8 +27,9 @@ process pool that reproduces the reference's process_in_batches, timed on this
 box's host cores) and "verified": the result records of the LAST TIMED step at a
 few batch positions are compared with what the oracle expects for those frames
 (expectations computed before the process touches the GPU); a mismatch is fatal
-on every rank (exit code 4) and no line is printed.  With the default modes of a
-full-suite workload the line also carries "api_end_to_end": the SAME clip through
+on every rank (exit code 4) and no line is printed.  A full-suite workload's line
+also carries "api_end_to_end": the SAME clip, in the workload's own modes (config keys
+ssim_mode / pixfmt / dct_mode / motion), through
 the reference-shaped Python entry point process_video_and_extract_metrics
 (video_processing.py:216 + :242: run_ffmpeg_metrics + calculate_average_scene_complexity,
 one pass) from HBM, from pinned host memory and from pageable host memory - the
@@ -40,6 +43,10 @@ Workloads (BASELINE.json configs):
       clip, through process_video_and_extract_metrics (PSNR/SSIM of all 300 frame pairs at 1080p + the complexity
       suite of every 10th frame at 64x64, full-frame DCT as the reference computes it at that size).  A step = one
       call on the clip; `value` = source frames/s with the clip resident in HBM, api_end_to_end = from host memory
+  c1ref  c1 with the REFERENCE's own definitions through the same entry point: the quality pair as decoded yuv420p planes
+      (what FFmpeg's psnr / ssim filters compare, video_processing.py:274-276) with vf_ssim's 8x8 integer windows, the
+      encoded stream's BGR frames beside it for the complexity suite (complexity_metrics.py:100) with Farneback motion (:340)
+      and the full-frame 64x64 DCT: config keys ssim_mode=ffmpeg, pixfmt=yuv420p, motion=farneback
   c3ref  1920x1080, the REFERENCE's own definitions in one line: Farneback motion (complexity_metrics.py:340),
       full-frame DCT energy + temporal L1 (:363, :574-579), FFmpeg vf_ssim + psnr on yuv420p planes
       (video_processing.py:275-276), gray + colour histograms, Canny, ORB count; 64 frames per step
@@ -71,6 +78,10 @@ WORKLOADS = {
     "c1": dict(h=1080, w=1920, batch=300, full=True, api=True,
                name="config.json defaults: 300 x 1920x1080 clip, resize 64x64, frame_interval=10, "
                     "process_video_and_extract_metrics = PSNR/SSIM(gauss) of every frame pair + complexity suite of every 10th frame"),
+    "c1ref": dict(h=1080, w=1920, batch=300, full=True, api=True, ref_true=True,
+                  name="config.json defaults with the REFERENCE's own definitions: 300 x 1920x1080 clip, resize 64x64, frame_interval=10, "
+                       "process_video_and_extract_metrics(r.yuv420p, d.yuv420p, encoded_bgr) = FFmpeg psnr + vf_ssim on the decoded Y,U,V planes "
+                       "of every frame pair + complexity suite of every 10th BGR frame with Farneback motion and the full-frame 64x64 DCT"),
     "c2": dict(h=1080, w=1920, batch=256, full=False,
                name="1920x1080 frame_interval=1 PSNR+SSIM(gauss 11x11)+8x8 DCT(energy+temporal), BGR24 pairs"),
     "c3": dict(h=1080, w=1920, batch=256, full=True,
@@ -486,54 +497,60 @@ API_LABELS = ("Advanced Motion Complexity", "DCT Complexity", "Temporal DCT Comp
 def api_rates(vp, cm, clips, config, steps, frames):
     """process_video_and_extract_metrics (the reference's caller of run_ffmpeg_metrics + calculate_average_scene_complexity,
     video_processing.py:216, :242) on the same clip held three ways; one warm call (allocations, the pinned ring), then
-    `steps` timed calls each.  -> {name_fps: ...}, {name: the last call's row}"""
+    `steps` timed calls each.  clips: name -> (input, encoded) BGR pair, or (input, encoded, encoded_bgr) = a planar quality
+    pair with the encoded stream's BGR frames beside it.  -> {name_fps: ...}, {name: the last call's row}"""
     import tempfile
     out, rows = {}, {}
     with tempfile.TemporaryDirectory() as tmp:
         csv = os.path.join(tmp, "bench_api.csv")
-        for name, (r, d) in clips.items():
-            metrics = vp.process_video_and_extract_metrics(r, d, config, csv_file=csv)
+        for name, clip in clips.items():
+            r, d = clip[0], clip[1]
+            kw = {"encoded_bgr": clip[2]} if len(clip) > 2 else {}
+            metrics = vp.process_video_and_extract_metrics(r, d, config, csv_file=csv, **kw)
             t0 = time.perf_counter()
             for _ in range(steps):
-                metrics = vp.process_video_and_extract_metrics(r, d, config, csv_file=csv)
+                metrics = vp.process_video_and_extract_metrics(r, d, config, csv_file=csv, **kw)
             out[name + "_fps"] = round(frames * steps / (time.perf_counter() - t0), 1)
             rows[name] = metrics
     return out, rows
 
 
-def api_rows_check(cm, rows, crec, dist_clip):
+def api_rows_check(cm, rows, crec, dist_clip, motion_mode=0):
     """The rows the entry point returned, against the C ABI's own (oracle-verified) records of the same frames: the last timed
     step measured frames 1..B of the clip against frames 0..B-1 - exactly the samples of the clip at frame_interval 1 - so
     pooling its records through the reference's tails must give the row's eight complexity values (counts and integer-derived
     values exactly, float sums to 1e-12: the entry point launches <= 100 frames at a time, the step 256), and the three
-    residences must agree with each other to the last bit."""
+    residences must agree with each other to the last bit.  One exception, documented in include/vqa.h: the Farneback mean is a
+    float sum whose grouping follows the chunk geometry (<= 1e-6 relative), and host chunks are capped in bytes."""
+    from rtvqa_amd import _native as N
     from rtvqa_amd import tails
-    series = {k: tails.scalars(k, crec) for k in ("motion", "dct", "hist", "edge", "orb", "color")}
+    series = {k: tails.scalars(k, crec, motion_mode) for k in ("motion", "dct", "hist", "edge", "orb", "color")}
     series["temporal"] = tails.scalars("temporal", crec)[1:]
     want = cm.pool_series(series, dist_clip, 1)
+    farneback = motion_mode == N.MOTION_FARNEBACK
     bad = []
     names = list(rows)
     for name in names:
         got = [rows[name][lab] for lab in API_LABELS]
         for k, (g, wv) in enumerate(zip(got, want)):
             g, wv = float(g), float(wv)
-            if not ((g != g and wv != wv) or abs(g - wv) <= 1e-12 * max(abs(wv), 1e-300)):
+            tol = 1e-6 if (farneback and k == 0) else 1e-12
+            if not ((g != g and wv != wv) or abs(g - wv) <= tol * max(abs(wv), 1e-300)):
                 bad.append("%s tuple[%d] %.17g vs %.17g" % (name, k, g, wv))
-        if any(rows[name][lab] != rows[names[0]][lab] for lab in API_LABELS + ("PSNR", "SSIM")):
-            bad.append("%s differs from %s" % (name, names[0]))
+        for lab in API_LABELS + ("PSNR", "SSIM"):
+            a, b = rows[name][lab], rows[names[0]][lab]
+            if a != b and not (a != a and b != b) and not (farneback and lab == API_LABELS[0] and abs(a - b) <= 1e-6 * abs(b)):
+                bad.append("%s differs from %s in %s" % (name, names[0], lab))
     return bad
 
 
-def api_end_to_end(rtvqa_amd, eng, ref_dev, dist_dev, ref_pin, dist_pin, h, w, steps, value, e2e_fps, config=None, crec=None):
+def api_end_to_end(clips, n, steps, value, e2e_fps, config, crec=None, dist_clip=None, motion_mode=0):
     """The drop-in Python surface on the measured path: resident / pinned host / pageable host clip of the workload's
-    geometry through process_video_and_extract_metrics.  Measured after the timed region; never `value`."""
+    geometry through process_video_and_extract_metrics, in the workload's own modes (config keys ssim_mode, pixfmt, dct_mode,
+    motion).  clips: name -> (input, encoded[, encoded_bgr]).  Measured after the timed region; never `value`."""
     from rtvqa_amd import complexity_metrics as cm
     from rtvqa_amd import video_processing as vp
-    n = dist_pin.shape[0]
-    config = config or {"crf": 23, "resize_width": w, "resize_height": h, "frame_interval": 1, "batch_size": 100}
-    ref_pg, dist_pg = np.array(ref_pin), np.array(dist_pin)  # ordinary (pageable) copies, as a caller that decoded a file holds them
-    rates, rows = api_rates(vp, cm, {"resident": (ref_dev, dist_dev), "host_pinned": (ref_pin, dist_pin),
-                                     "host_pageable": (ref_pg, dist_pg)}, config, steps, n)
+    rates, rows = api_rates(vp, cm, clips, config, steps, n)
     cm.release_buffers()  # the pinned ring and lane buffers of the passes: given back (stream.release_buffers)
     m = rows["resident"]
     out = dict(rates, frames_per_call=n, calls=steps, config=config,
@@ -541,9 +558,10 @@ def api_end_to_end(rtvqa_amd, eng, ref_dev, dist_dev, ref_pin, dist_pin, h, w, s
                            "calculate_average_scene_complexity in ONE pass; stats files, regex parse and CSV row included)",
                PSNR=m.get("PSNR"), SSIM=m.get("SSIM"))
     if crec is not None:
-        bad = api_rows_check(cm, rows, crec, dist_dev)
+        bad = api_rows_check(cm, rows, crec, dist_clip, motion_mode)
         out["verified"] = {"ok": not bad, "checker": "the C ABI's last timed step (itself verified against the oracle) pooled through the "
-                                                     "reference's tails: the row's eight complexity values to 1e-12, the three residences bit for bit"}
+                                                     "reference's tails: the row's eight complexity values to 1e-12 (Farneback mean 1e-6), "
+                                                     "the three residences bit for bit (Farneback mean 1e-6)"}
         if bad:  # (the caller prints no line and exits 4 after the ranks' final barrier: no rank is left hanging)
             sys.stderr.write("[bench] FATAL: the entry point's row differs from the C ABI's records: %s\n" % json.dumps(bad[:8]))
             sys.stderr.flush()
@@ -567,6 +585,7 @@ def _free_port():
 # reference-shaped entry points.
 # ---------------------------------------------------------------------------
 C1_CONFIG = {"crf": 23, "resize_width": 64, "resize_height": 64, "frame_interval": 10, "batch_size": 100}  # /root/reference/config.json
+C1REF_KEYS = {"ssim_mode": "ffmpeg", "pixfmt": "yuv420p", "motion": "farneback"}  # (dct_mode auto = the reference's full-frame DCT at 64x64)
 
 
 def _c1_quality_item(pair):
@@ -576,78 +595,102 @@ def _c1_quality_item(pair):
     return pl.frame_quality(ref, dist, bgr_planes(ref.shape[0], ref.shape[1]), "gauss")
 
 
+def _c1ref_quality_item(item):
+    from oracle import pipeline as pl
+    from rtvqa_amd.engine import yuv420p_planes
+    ref, dist, h, w = item
+    return pl.frame_quality(ref, dist, yuv420p_planes(h, w), "ffmpeg")
+
+
 def c1_clip(rank, h, w, n):
     from rtvqa_amd import synth
     parts = [stream_chunk("natural", rank, h, w, a, min(CHUNK, n - a)) for a in range(0, n, CHUNK)]
     return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
 
-def c1_oracle(ref, dist, workers, pool=True):
+def c1_planar(clip):
+    """the clip as the decoded yuv420p planes FFmpeg's filters would compare (frames.bgr_to_yuv420p, chunked)"""
+    from rtvqa_amd.frames import bgr_to_yuv420p
+    return np.concatenate([bgr_to_yuv420p(clip[a:a + CHUNK]) for a in range(0, len(clip), CHUNK)])
+
+
+def c1_oracle(ref, dist, workers, pool=True, planar=None):
     """The reference's two calls on the clip, restated on the CPU: the quality filters over every frame pair (the ffmpeg
     subprocess of video_processing.py:270-297 - here the oracle's PSNR/SSIM under the same process pool) and
     calculate_average_scene_complexity with its own dispatcher (a NEW pool per metric pass, complexity_metrics.py:143).
+    planar = (yref, ydist): the reference-true definitions (vf_ssim on the yuv420p planes, Farneback motion).
     -> (8-tuple, [(sse, ssim)] per frame)"""
     from concurrent.futures import ProcessPoolExecutor
     from oracle import pipeline as pl
     cfg = C1_CONFIG
-    items = [(ref[i], dist[i]) for i in range(len(ref))]
+    if planar is not None:
+        h, w = dist.shape[1], dist.shape[2]
+        items, fn = [(planar[0][i], planar[1][i], h, w) for i in range(len(ref))], _c1ref_quality_item
+    else:
+        items, fn = [(ref[i], dist[i]) for i in range(len(ref))], _c1_quality_item
     if pool:
         q = []
         with ProcessPoolExecutor(max_workers=workers) as ex:
             for i in range(0, len(items), 100):
-                q.extend(ex.map(_c1_quality_item, items[i:i + 100]))
+                q.extend(ex.map(fn, items[i:i + 100]))
     else:
-        q = [_c1_quality_item(it) for it in items]
+        q = [fn(it) for it in items]
     tup = pl.calculate_average_scene_complexity(list(dist), cfg["resize_width"], cfg["resize_height"], cfg["frame_interval"],
                                                 num_workers=workers, batch_size=cfg["batch_size"], dct_mode="full",
-                                                dispatcher=pl.process_in_batches if pool else pl.serial_map)
+                                                dispatcher=pl.process_in_batches if pool else pl.serial_map,
+                                                motion="farneback" if planar is not None else "sad")
     return tup, q
 
 
-def cpu_baseline_c1(ref, dist):
+def cpu_baseline_c1(ref, dist, planar=None):
     """ref/dist: the clip or its first frames (0.35 s of CPU work per frame pair for PSNR/SSIM, 0.36 s per selected frame
-    for the complexity suite: the 300-frame clip is ~115 s of CPU work spread over the pool)"""
+    for the complexity suite: the 300-frame clip is ~115 s of CPU work spread over the pool; reference-true definitions:
+    7 ms per pair for psnr + vf_ssim on the planes, 0.7 s more per selected pair for Farneback: ~35 s)"""
     from oracle import c_oracle as co
     co.build()
     cores = visible_cores()
     workers, override = cpu_workers(cores)
     sample = len(ref)
     t0 = time.perf_counter()
-    tup, q = c1_oracle(ref, dist, workers)
+    tup, q = c1_oracle(ref, dist, workers, planar=planar)
     dt = time.perf_counter() - t0
-    # `cores` = the worker processes that actually ran (the contract's "threads you actually used"); visible_cores = what
-    # os.sched_getaffinity shows the process, which is what the reference's cpu_count() // 2 rule starts from
+    # `cores` = the cores that actually ran it (finish_cpu_line); visible_cores = what os.sched_getaffinity shows the
+    # process, which is what the reference's cpu_count() // 2 rule starts from
     line = dict(value=round(sample / dt, 3), unit="frames/s", cores=workers, visible_cores=cores, workers=workers, workers_override=override,
                 cgroup_cpu_limit=cgroup_cpu_limit(), kind="port", seconds=round(dt, 2),
-                sample="%d frames of the same clip through oracle/pipeline.py: PSNR/SSIM of every frame "
+                sample="%d frames of the same clip through oracle/pipeline.py: %s of every frame "
                        "pair under ProcessPoolExecutor(max_workers=cores//2 = %d of %d visible cores), then "
-                       "calculate_average_scene_complexity with the reference's dispatcher (a new pool per "
-                       "metric pass, chunksize 1, batch_size 100)" % (sample, workers, cores))
+                       "calculate_average_scene_complexity%s with the reference's dispatcher (a new pool per "
+                       "metric pass, chunksize 1, batch_size 100)"
+                       % (sample, "psnr + vf_ssim on the yuv420p planes" if planar is not None else "PSNR/SSIM", workers, cores,
+                          " (Farneback motion)" if planar is not None else ""))
 
     def again(wk, m):
         t1 = time.perf_counter()
-        c1_oracle(ref[:m], dist[:m], wk)
+        c1_oracle(ref[:m], dist[:m], wk, planar=(planar[0][:m], planar[1][:m]) if planar is not None else None)
         return time.perf_counter() - t1
     line.update(second_cpu_figure(workers, override, again, min(sample, 200)))
     return (sample, tup, q), finish_cpu_line(line)
 
 
 def main_c1(args, rank, local_rank, world):
-    wl = WORKLOADS["c1"]
+    wl = WORKLOADS[args.workload]
+    rt = bool(wl.get("ref_true"))  # c1ref: the reference's own definitions (planar quality pair + BGR stream, vf_ssim, Farneback)
     h, w = wl["h"], wl["w"]
     n = args.batch or wl["batch"]
-    cfg = dict(C1_CONFIG)
+    cfg = dict(C1_CONFIG, **(C1REF_KEYS if rt else {}))
     if args.stub_engine:
-        raise SystemExit("--stub-engine rehearses the rank logic of the C-ABI workloads; c1 has no stub")
+        raise SystemExit("--stub-engine rehearses the rank logic of the C-ABI workloads; %s has no stub" % args.workload)
     # ---- CPU first (its pools fork before this process touches the GPU): baseline on rank 0 at N = 1, and the expectation
     expect, cpu_line = None, None
     ref_h, dist_h = c1_clip(rank, h, w, n)  # ordinary host arrays: what a caller that decoded two files holds
+    yref_h, ydist_h = (c1_planar(ref_h), c1_planar(dist_h)) if rt else (None, None)
     if world == 1 and rank == 0 and args.cpu_sample != 0:
-        ns = min(n, args.cpu_sample if args.cpu_sample > 0 else n)  # default: the WHOLE clip (300 frames: ~105 s of CPU work over the pool)
-        expect, cpu_line = cpu_baseline_c1(ref_h[:ns], dist_h[:ns])
+        ns = min(n, args.cpu_sample if args.cpu_sample > 0 else n)  # default: the WHOLE clip (300 frames: ~105 s / ~35 s of CPU work over the pool)
+        expect, cpu_line = cpu_baseline_c1(ref_h[:ns], dist_h[:ns], (yref_h[:ns], ydist_h[:ns]) if rt else None)
     elif args.verify:
         nv = min(n, 30)
-        expect = (nv,) + c1_oracle(ref_h[:nv], dist_h[:nv], 1, pool=False)
+        expect = (nv,) + c1_oracle(ref_h[:nv], dist_h[:nv], 1, pool=False, planar=(yref_h[:nv], ydist_h[:nv]) if rt else None)
 
     rehearsal = "VQA_BENCH_DEVICE" in os.environ
     device = int(os.environ.get("VQA_BENCH_DEVICE", local_rank))
@@ -670,7 +713,7 @@ def main_c1(args, rank, local_rank, world):
     from rtvqa_amd import complexity_metrics as cm
     from rtvqa_amd import stream, synth
     from rtvqa_amd import video_processing as vp
-    from rtvqa_amd.engine import bgr_planes
+    from rtvqa_amd.engine import DeviceFrames, bgr_planes, yuv420p_planes
     eng = cm.get_engine(device)
     if args.inflight == 1:  # the serial configuration (profiling runs): every chunk on the one default engine, in order
         stream.MAX_LANES = 1
@@ -679,13 +722,32 @@ def main_c1(args, rank, local_rank, world):
     ref_pin, dist_pin = eng.alloc_pinned((n, h, w, 3)), eng.alloc_pinned((n, h, w, 3))
     ref_pin[...] = ref_h
     dist_pin[...] = dist_h
-    ref_dev, dist_dev = eng.upload(ref_pin), eng.upload(dist_pin)
+    dist_dev = eng.upload(dist_pin)
+    if rt:
+        yb = yref_h.shape[1]
+        yref_pin, ydist_pin = eng.alloc_pinned((n, yb)), eng.alloc_pinned((n, yb))
+        yref_pin[...] = yref_h
+        ydist_pin[...] = ydist_h
+
+        def planar_dev(a):
+            d = eng.upload(a.reshape(n, 1, yb))
+            return DeviceFrames(d.ptr, n, h, w, frame_stride=yb, row_stride=w, owner=d, channels=1)
+        yref_dev, ydist_dev = planar_dev(yref_pin), planar_dev(ydist_pin)
+        resident = (yref_dev, ydist_dev, dist_dev)
+        host_clips = {"host_pinned": (yref_pin, ydist_pin, dist_pin), "host_pageable": (yref_h, ydist_h, dist_h)}
+        planes, smode, motion_mode = yuv420p_planes(h, w), N.SSIM_FFMPEG, N.MOTION_FARNEBACK
+    else:
+        ref_dev = eng.upload(ref_pin)
+        resident = (ref_dev, dist_dev)
+        host_clips = {"host_pinned": (ref_pin, dist_pin), "host_pageable": (ref_h, dist_h)}
+        planes, smode, motion_mode = bgr_planes(h, w), N.SSIM_GAUSS, N.MOTION_SAD
     import tempfile
     tmp = tempfile.mkdtemp(prefix="vqa_c1_")
     csv = os.path.join(tmp, "c1.csv")
+    kw = {"encoded_bgr": resident[2]} if rt else {}
 
     def step():
-        return vp.process_video_and_extract_metrics(ref_dev, dist_dev, cfg, csv_file=csv)
+        return vp.process_video_and_extract_metrics(resident[0], resident[1], cfg, csv_file=csv, **kw)
 
     def fence():
         for e in stream.get_engine_pair(device):
@@ -706,18 +768,20 @@ def main_c1(args, rank, local_rank, world):
     dt = time.perf_counter() - t0
 
     # ---- serial pass for the per-kernel table: the same pass on ONE context, overlap off, HIP-event profiling on
-    planes = bgr_planes(h, w)
     prof, dt_serial = {}, None
     if args.serial_pass and args.steps > 0:
         eng.set_overlap(False)
-        qual = stream.Quality(planes, N.SSIM_GAUSS)
-        cx = stream.Complexity((cfg["resize_width"], cfg["resize_height"]), cfg["frame_interval"])
-        stream.run(dist_dev, ref_dev, qual, cx, cfg["batch_size"], engine=eng)
+        qual = stream.Quality(planes, smode)
+        cx = stream.Complexity((cfg["resize_width"], cfg["resize_height"]), cfg["frame_interval"], motion_mode=motion_mode)
+
+        def serial():
+            return stream.run(dist_dev, resident[0], qual, cx, cfg["batch_size"], engine=eng, qdist=resident[1] if rt else None)
+        serial()
         eng.profile(True)
         eng.profile_read(reset=True)
         ts = time.perf_counter()
         for _ in range(args.steps):
-            stream.run(dist_dev, ref_dev, qual, cx, cfg["batch_size"], engine=eng)
+            serial()
         eng.sync()
         dt_serial = time.perf_counter() - ts
         prof = eng.profile_read(reset=True)
@@ -730,28 +794,34 @@ def main_c1(args, rank, local_rank, world):
         nv, tup, q = expect
         bad = []
         got = cm.calculate_average_scene_complexity(dist_dev.slice(0, nv), cfg["resize_width"], cfg["resize_height"],
-                                                    frame_interval=cfg["frame_interval"], batch_size=cfg["batch_size"])
+                                                    frame_interval=cfg["frame_interval"], batch_size=cfg["batch_size"],
+                                                    motion=cfg.get("motion"))
         for k, (g, wv) in enumerate(zip(got, tup)):
             g, wv = float(g), float(wv)
             tol = 1e-12 if k in (2, 3, 4, 5, 7) else 1e-4   # counts + the reference's own NumPy tails | DCT, motion floats
             if not ((g != g and wv != wv) or abs(g - wv) <= tol * max(abs(wv), 1e-30)):
                 bad.append("tuple[%d] %.12g vs %.12g" % (k, g, wv))
-        sse, ssim, _sizes = vp.frame_quality(ref_dev.slice(0, nv), dist_dev.slice(0, nv))
+        if rt:
+            sse, ssim, sizes = vp.frame_quality(resident[0].slice(0, nv), resident[1].slice(0, nv), "yuv420p", "ffmpeg", h, w)
+        else:
+            sse, ssim, sizes = vp.frame_quality(resident[0].slice(0, nv), resident[1].slice(0, nv))
         for i, (es, em) in enumerate(q):
             if [int(v) for v in sse[i]] != [int(v) for v in es]:
                 bad.append("frame %d sse %s != %s" % (i, sse[i].tolist(), es))
             if any(abs(float(a) - float(b)) > 1e-4 * abs(float(b)) for a, b in zip(ssim[i], em)):
                 bad.append("frame %d ssim %s vs %s" % (i, ssim[i].tolist(), em))
-        # the row the timed call returned: first-frame PSNR / SSIM as the stats files print them
+        # the row the timed call returned: first-frame PSNR / SSIM as the stats files print them (area-weighted over the planes)
         es, em = q[0]
-        mse = sum(es) / (3.0 * h * w)
-        if abs(metrics["PSNR"] - 10.0 * np.log10(255.0 ** 2 / mse)) > 6e-3 or abs(metrics["SSIM"] - sum(em) / 3.0) > 1e-4:
+        areas = [float(sw * sh) for sw, sh in sizes]
+        mse = sum(e / a * (a / sum(areas)) for e, a in zip(es, areas))
+        allv = sum(v * (a / sum(areas)) for v, a in zip(em, areas))
+        if abs(metrics["PSNR"] - 10.0 * np.log10(255.0 ** 2 / mse)) > 6e-3 or abs(metrics["SSIM"] - allv) > 1e-4:
             bad.append("row PSNR/SSIM %r %r" % (metrics["PSNR"], metrics["SSIM"]))
         verified = {"frames": nv, "ok": not bad, "checker": "oracle/pipeline.py on the first %d frames of the clip (computed before GPU init)" % nv,
                     "fields": "8-tuple: histogram/edge/orb/colour-histogram/frame-rate slots 1e-12 (exact counts + the reference's NumPy "
                               "tails), motion/dct/temporal 1e-4; per frame: sse exact, ssim 1e-4; the CSV row's PSNR/SSIM"}
         if bad:
-            sys.stderr.write("[bench] rank %d: FATAL: c1 output differs from the oracle: %s\n" % (rank, json.dumps(bad[:8])))
+            sys.stderr.write("[bench] rank %d: FATAL: %s output differs from the oracle: %s\n" % (rank, args.workload, json.dumps(bad[:8])))
             sys.stderr.flush()
         if dist_on:
             nbad = torch.tensor([float(len(bad))], dtype=torch.float64, device=red_dev)
@@ -767,38 +837,59 @@ def main_c1(args, rank, local_rank, world):
     c1_bad = False
     if rank == 0:
         P = h * w
-        fpl = float(n) / max(1, -(-n // cfg["batch_size"]))  # frame pairs per quality launch (chunks of batch_size)
-        alg = {"k_ssim_gauss": int(6 * P * fpl)}
-        kernels, roof = kernel_report(prof, alg, {"k_ssim_gauss": int(88 * P * 3 * fpl)}, {}, "c1", fpl, False)
+        nchunks = max(1, -(-n // cfg["batch_size"]))
+        fpl = float(n) / nchunks  # frame pairs per quality launch (chunks of batch_size)
+        pairs = max(len(cm.selected_indices(n, cfg["frame_interval"])) - 1, 0)
+        if rt:
+            # vf_ssim on yuv420p: three planar launches per chunk, 3P bytes in all -> P per frame and launch; Farneback: 279 B per
+            # level-0 pixel and pair (the figure derived in main() for c3ref), ~pairs/chunks pairs per launch
+            alg = {"k_ssim_ffmpeg": int(P * fpl), "farneback(pyramid)": int(279 * P * pairs / nchunks)}
+            fma = {}
+        else:
+            alg = {"k_ssim_gauss": int(6 * P * fpl)}
+            fma = {"k_ssim_gauss": int(88 * P * 3 * fpl)}
+        kernels, roof = kernel_report(prof, alg, fma, {}, args.workload, fpl, False)
         line = {"metric": "frames/sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": max(args.warmup, 1), "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4),
                 "ms_per_step_serial": round(dt_serial / args.steps * 1e3, 4) if dt_serial else None,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->f32 (SSE/bins/SAD exact int)",
-                "data": "synthetic (synth.s_natural v%d, seed 1234, one %d-frame clip per GPU; distorted = +-3 grey levels)"
-                        % (synth.GENERATOR_VERSION, n),
-                "config": {"workload": wl["name"], "id": "c1", "frames_per_step_per_gpu": n, "reference_config": cfg,
+                "data": "synthetic (synth.s_natural v%d, seed 1234, one %d-frame clip per GPU; distorted = +-3 grey levels%s)"
+                        % (synth.GENERATOR_VERSION, n, "; yuv420p planes derived by frames.bgr_to_yuv420p" if rt else ""),
+                "config": {"workload": wl["name"], "id": args.workload, "frames_per_step_per_gpu": n, "reference_config": cfg,
                            "selected_frames": len(cm.selected_indices(n, cfg["frame_interval"])),
-                           "entry_point": "rtvqa_amd.video_processing.process_video_and_extract_metrics",
+                           "entry_point": "rtvqa_amd.video_processing.process_video_and_extract_metrics"
+                                          + ("(yref, ydist, config, encoded_bgr=...)" if rt else ""),
                            "collective": ("%s scalar all-reduce" % ("rccl" if backend_used == "nccl" else "gloo")) if dist_on else "none",
                            "backend": backend_used, "rccl_ranks": rccl_ranks, "devices": devices, "resident": "HBM",
-                           "ssim_mode": "gauss", "pixfmt": "bgr24", "dct_mode": "auto (full-frame at 64x64, as cv2.dct)",
-                           "motion": "sad", "parallelism": "1 clip/GPU x%d" % world, "lanes": stream.MAX_LANES,
-                           "overlap": bool(args.overlap), "cpu_affinity": affinity},
+                           "ssim_mode": cfg.get("ssim_mode", "gauss"), "pixfmt": cfg.get("pixfmt", "bgr24"),
+                           "dct_mode": "auto (full-frame at 64x64, as cv2.dct)",
+                           "motion": cfg.get("motion", "sad"), "parallelism": "1 clip/GPU x%d" % world,
+                           "lanes": 1 if rt else stream.MAX_LANES,   # (Farneback: one context, stream.run)
+                           "overlap": bool(args.overlap), "cpu_affinity": affinity,
+                           "launched_by": "bench.py itself (--gpus N without a launcher)" if os.environ.get("VQA_BENCH_LAUNCHED") else
+                                          ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "direct")},
                 "roofline": roof, "kernels": kernels,
                 "serial": {"ms_per_step": round(dt_serial / args.steps * 1e3, 4), "fps": round(n * args.steps / dt_serial, 1),
                            "what": "the same pass (stream.run) on ONE context, VQA_OPT_OVERLAP off, HIP-event profiling on"} if dt_serial else None,
                 "row": {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in metrics.items()
                         if k in ("PSNR", "SSIM", "Resolution (px)")}}
         if args.api_steps > 0:
-            rates, rows = api_rates(vp, cm, {"host_pinned": (ref_pin, dist_pin), "host_pageable": (ref_h, dist_h)}, cfg, args.api_steps, n)
-            same = all(rows[k][lab] == metrics[lab] for k in rows for lab in API_LABELS + ("PSNR", "SSIM"))
+            rates, rows = api_rates(vp, cm, host_clips, cfg, args.api_steps, n)
+            # Farneback's mean is a float sum whose grouping follows the chunk geometry (include/vqa.h), and host chunks are
+            # capped in bytes where resident ones are not: that one label may differ in its last digits
+            loose = ("Advanced Motion Complexity",) if rt else ()
+            same = all(rows[k][lab] == metrics[lab] or (lab in loose and abs(rows[k][lab] - metrics[lab]) <= 1e-6 * abs(metrics[lab]))
+                       for k in rows for lab in API_LABELS + ("PSNR", "SSIM"))
             if not same:
-                sys.stderr.write("[bench] FATAL: c1 rows from host memory differ from the resident clip's row\n")
+                sys.stderr.write("[bench] FATAL: %s rows from host memory differ from the resident clip's row\n" % args.workload)
                 c1_bad = True
+            per_frame = (2 * yref_h.shape[1] + 3 * P / cfg["frame_interval"]) if rt else 2 * 3 * P
             line["api_end_to_end"] = dict(rates, rows_identical_to_resident=same, resident_fps=round(value / world, 1), frames_per_call=n, calls=args.api_steps,
-                                          bytes_per_frame=2 * 3 * P,
-                                          note="the same call from host memory: both 1080p streams cross PCIe once (12.4 MB per frame "
-                                               "pair), the complexity kernels read every 10th frame of the uploaded chunk")
+                                          bytes_per_frame=int(per_frame),
+                                          note=("the same call from host memory: both yuv420p streams cross PCIe once (6.2 MB per frame pair) "
+                                                "and every 10th BGR frame of the encoded stream (0.6 MB per source frame)") if rt else
+                                               ("the same call from host memory: both 1080p streams cross PCIe once (12.4 MB per frame "
+                                                "pair), the complexity kernels read every 10th frame of the uploaded chunk"))
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         if verified is not None:
@@ -971,7 +1062,7 @@ def main():
 
     # CPU baseline first: its worker processes are forked before this process touches the GPU.  The same leg
     # computes the oracle's expected records for a few frames of this rank's stream (the checker of "verified").
-    if args.workload == "c1":
+    if wl.get("api"):   # c1 / c1ref: the reference's own config.json through the entry point
         return main_c1(args, rank, local_rank, world)
     cpu_line, expect = None, {}
     yuv = args.pixfmt == "yuv420p"
@@ -1049,14 +1140,15 @@ def main():
             yref_buf, ydist_buf = DeviceBuffer(eng, ybytes * (B + 1)), DeviceBuffer(eng, ybytes * (B + 1))
         do_e2e = rank == 0 and args.e2e_steps > 0
         default_modes = (args.ssim_mode == "gauss" and not yuv and args.motion == "sad" and args.dct_mode == "block8")
-        do_api = rank == 0 and args.api_steps > 0 and full and default_modes
+        # (every full-suite workload in ITS OWN modes: the entry point takes them as config keys)
+        do_api = rank == 0 and args.api_steps > 0 and full
         Be = min(args.e2e_batch, B)
         Bh = B if do_api else Be  # host copies: the whole clip for the API legs, else the end_to_end batch
         yref_pin = ydist_pin = None
         if do_e2e or do_api:  # page-locked host copies of the first Bh+1 frames (end_to_end reads the first Be+1 of them)
             ref_pin, dist_pin = eng.alloc_pinned((Bh + 1, h, w, 3)), eng.alloc_pinned((Bh + 1, h, w, 3))
             if yuv:  # the quality kernels' planar inputs cross PCIe too (the reference stream only in that form)
-                yref_pin, ydist_pin = eng.alloc_pinned((Be + 1, ybytes)), eng.alloc_pinned((Be + 1, ybytes))
+                yref_pin, ydist_pin = eng.alloc_pinned((Bh + 1, ybytes)), eng.alloc_pinned((Bh + 1, ybytes))
         for a in range(0, B + 1, CHUNK):
             n = min(CHUNK, B + 1 - a)
             r, d = stream_chunk(args.content, rank, h, w, a, n)
@@ -1071,11 +1163,10 @@ def main():
                 m = min(n, Bh + 1 - a)
                 ref_pin[a:a + m] = r[:m]
                 dist_pin[a:a + m] = d[:m]
-            if do_e2e and a <= Be:
-                m = min(n, Be + 1 - a)
-                if yuv:
-                    yref_pin[a:a + m] = yr[:m].reshape(m, ybytes)
-                    ydist_pin[a:a + m] = yd[:m].reshape(m, ybytes)
+            if (do_e2e or do_api) and a <= Bh and yuv:
+                m = min(n, Bh + 1 - a)
+                yref_pin[a:a + m] = yr[:m].reshape(m, ybytes)
+                ydist_pin[a:a + m] = yd[:m].reshape(m, ybytes)
         ref_all = DeviceFrames(ref_buf.ptr, B + 1, h, w, owner=ref_buf)
         dist_all = DeviceFrames(dist_buf.ptr, B + 1, h, w, owner=dist_buf)
         ref_b, dist_b, prev0 = ref_all.slice(1, B + 1), dist_all.slice(1, B + 1), dist_all.frame(0)
@@ -1281,13 +1372,24 @@ def main():
                          "config": config, "roofline": roof, "kernels": kernels, "serial": serial})
             if do_e2e:
                 line["end_to_end"] = end_to_end(rtvqa_amd, N, device, eng, ref_pin[:Be + 1], dist_pin[:Be + 1], h, w, full, mask,
-                                                params, planes, smode, args.e2e_steps, yref_pin, ydist_pin)
+                                                params, planes, smode, args.e2e_steps,
+                                                yref_pin[:Be + 1] if yuv else None, ydist_pin[:Be + 1] if yuv else None)
             if do_api:
-                line["api_end_to_end"] = api_end_to_end(rtvqa_amd, eng, ref_all, dist_all, ref_pin, dist_pin, h, w, args.api_steps,
-                                                        value, line.get("end_to_end", {}).get("fps"),
-                                                        crec=c if (args.verify and args.steps > 0) else None)
+                api_cfg = {"crf": 23, "resize_width": w, "resize_height": h, "frame_interval": 1, "batch_size": 100,
+                           "ssim_mode": args.ssim_mode, "pixfmt": args.pixfmt, "dct_mode": args.dct_mode, "motion": args.motion}
+                if yuv:  # the planar quality pair + the encoded stream's BGR frames, each held three ways
+                    yref_all = DeviceFrames(yref_buf.ptr, B + 1, h, w, frame_stride=ybytes, row_stride=w, owner=yref_buf, channels=1)
+                    ydist_all = DeviceFrames(ydist_buf.ptr, B + 1, h, w, frame_stride=ybytes, row_stride=w, owner=ydist_buf, channels=1)
+                    clips = {"resident": (yref_all, ydist_all, dist_all), "host_pinned": (yref_pin, ydist_pin, dist_pin),
+                             "host_pageable": (np.array(yref_pin), np.array(ydist_pin), np.array(dist_pin))}
+                else:  # ordinary (pageable) copies, as a caller that decoded a file holds them
+                    clips = {"resident": (ref_all, dist_all), "host_pinned": (ref_pin, dist_pin),
+                             "host_pageable": (np.array(ref_pin), np.array(dist_pin))}
+                line["api_end_to_end"] = api_end_to_end(clips, B + 1, args.api_steps, value, line.get("end_to_end", {}).get("fps"), api_cfg,
+                                                        crec=c if (args.verify and args.steps > 0) else None, dist_clip=dist_all,
+                                                        motion_mode=params.motion_mode)
             elif rank == 0 and args.api_steps > 0:
-                line["api_end_to_end"] = None  # (c2 / non-default modes: process_video_and_extract_metrics runs the default full suite)
+                line["api_end_to_end"] = None  # (c2 is not a full suite: process_video_and_extract_metrics always runs one)
             if cpu_line is not None:
                 line["cpu_baseline"] = cpu_line
             if verified is not None:

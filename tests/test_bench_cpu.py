@@ -185,6 +185,30 @@ def test_c1_is_a_workload_and_refuses_the_stub():
     assert r.returncode != 0 and "c1 has no stub" in (r.stderr + r.stdout)
 
 
+def test_c1ref_is_c1_with_the_references_own_definitions():
+    """c1ref = config.json's five keys plus the three that select what the reference itself computes: FFmpeg's filters on the
+    decoded yuv420p planes (video_processing.py:274-276) and Farneback motion (complexity_metrics.py:340); and its CPU side
+    - the oracle pipeline with the same definitions - runs here on a tiny clip."""
+    import numpy as np
+    from rtvqa_amd import synth, video_processing as vp
+    wl = bench.WORKLOADS["c1ref"]
+    assert wl["ref_true"] and wl["api"] and (wl["h"], wl["w"], wl["batch"]) == (1080, 1920, 300)
+    cfg = dict(bench.C1_CONFIG, **bench.C1REF_KEYS)
+    vp.validate_config(cfg)
+    assert (cfg["ssim_mode"], cfg["pixfmt"], cfg["motion"]) == ("ffmpeg", "yuv420p", "farneback")
+    r = _run([sys.executable, "bench.py", "--workload", "c1ref", "--stub-engine", "--backend", "gloo"])
+    assert r.returncode != 0 and "c1ref has no stub" in (r.stderr + r.stdout)
+    ref = synth.s_natural(21, 72, 96, seed=3)
+    dist = synth.distort(ref)
+    yr, yd = bench.c1_planar(ref), bench.c1_planar(dist)
+    assert yr.shape == (21, 72 * 96 * 3 // 2)
+    tup, q = bench.c1_oracle(ref, dist, 1, pool=False, planar=(yr, yd))
+    tup_sad, q_bgr = bench.c1_oracle(ref, dist, 1, pool=False)
+    assert len(q) == 21 and len(q[0][0]) == 3 and len(tup) == 8
+    assert tup[0] != tup_sad[0] and tup[1:] == tup_sad[1:]          # only the motion slot changes with the motion definition
+    assert q[0][0] != q_bgr[0][0]                                   # other planes, other sums
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_gpus_n_without_a_launcher_starts_n_ranks(world):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: the parent touches no GPU, starts the N ranks as
