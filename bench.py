@@ -669,7 +669,8 @@ def cpu_baseline_c1(ref, dist, planar=None):
         t1 = time.perf_counter()
         c1_oracle(ref[:m], dist[:m], wk, planar=(planar[0][:m], planar[1][:m]) if planar is not None else None)
         return time.perf_counter() - t1
-    line.update(second_cpu_figure(workers, override, again, min(sample, 200)))
+    # (the reference-true clip is ~35 s of CPU work in all: its second figure runs the whole sample, not half of it)
+    line.update(second_cpu_figure(workers, override, again, min(sample, 200) if planar is None else 2 * sample))
     return (sample, tup, q), finish_cpu_line(line)
 
 
@@ -925,61 +926,7 @@ def launch_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def _parse_cpulist(text):
-    cpus = set()
-    for part in text.strip().split(","):
-        if not part:
-            continue
-        a, _, b = part.partition("-")
-        cpus.update(range(int(a), int(b or a) + 1))
-    return cpus
-
-
-def gpu_local_cpus(index, sysfs="/sys"):
-    """The CPUs local to HIP device `index` (its NUMA node), from sysfs alone - no GPU call: KFD topology nodes in node order
-    are the HIP devices in device order; each names its PCI function (domain, location_id = bus << 8 | devfn), whose
-    local_cpulist is the answer.  -> (set of cpus, source path) or (None, reason)."""
-    vis = next((os.environ[k] for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if os.environ.get(k)), None)
-    if vis is not None:
-        try:
-            index = [int(x) for x in vis.split(",")][index]
-        except (ValueError, IndexError):
-            return None, "device visibility list %r is not a plain index list" % vis
-    nodes_dir = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
-    try:
-        gpus = []
-        for node in sorted(os.listdir(nodes_dir), key=int):
-            props = dict(line.split()[:2] for line in open(os.path.join(nodes_dir, node, "properties")) if len(line.split()) >= 2)
-            if int(props.get("simd_count", "0")) > 0:
-                gpus.append(props)
-        pr = gpus[index]
-        loc, dom = int(pr["location_id"]), int(pr.get("domain", "0"))
-        path = os.path.join(sysfs, "bus", "pci", "devices", "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7),
-                            "local_cpulist")
-        cpus = _parse_cpulist(open(path).read())
-        return (cpus, path) if cpus else (None, "empty " + path)
-    except (OSError, ValueError, KeyError, IndexError) as e:
-        return None, "sysfs: %s" % e
-
-
-def bind_numa(device, enabled=True, sysfs="/sys"):
-    """--bind-numa: pin this rank (and the copier threads it will start) to the CPUs of its GPU's NUMA node BEFORE any GPU
-    call.  With eight ranks feeding eight GPUs over PCIe, a copier thread on the far socket halves its bandwidth.
-    -> the record for config.cpu_affinity."""
-    if not enabled:
-        return {"bound": False, "why": "--no-bind-numa"}
-    if not hasattr(os, "sched_setaffinity"):
-        return {"bound": False, "why": "no sched_setaffinity on this platform"}
-    cpus, src = gpu_local_cpus(device, sysfs)
-    if cpus is None:
-        return {"bound": False, "why": src}
-    have = os.sched_getaffinity(0)
-    want = cpus & have
-    if not want:
-        return {"bound": False, "why": "the GPU's local CPUs %s are outside this process's affinity" % sorted(cpus)[:4]}
-    if want != have:
-        os.sched_setaffinity(0, want)
-    return {"bound": True, "cpus": len(want), "of_visible": len(have), "first": min(want), "last": max(want), "source": src}
+from rtvqa_amd.affinity import _parse_cpulist, bind_numa, gpu_local_cpus  # noqa: E402,F401  (sysfs only: no GPU call, no torch)
 
 
 # ---------------------------------------------------------------------------

@@ -175,11 +175,11 @@ typedef struct vqa_plane_desc {
 
 typedef struct vqa_plane_metrics {
     uint64_t sse;   /* sum (ref - dist)^2 over the plane — FFmpeg psnr's per-component sum */
-    double   ssim;  /* mean SSIM of the plane in the selected ssim_mode.  The SSIM map is summed per row strip and
-                       the strip count follows the launch's workgroup count (frames x planes x column blocks), so on
-                       planes taller than 74 rows the same frame pair submitted in batches of different size can
-                       differ in the last digits (<= 1e-8 relative: 1.4e-9 measured at 1080p between launches of 3
-                       and 25 frames, 6e-10 at 4320x7680); the same batch always gives the same bits; sse is exact */
+    double   ssim;  /* mean SSIM of the plane in the selected ssim_mode.  Independent of how frames are batched: the Gaussian
+                       kernel sums the SSIM map in 2^-27 fixed point (integer sums are associative, so the strip geometry a
+                       launch picks from its workgroup count cannot show; rounds 1-5 summed floats and differed by <= 1e-8
+                       between batch sizes); vf_ssim's samples are summed in double, exactly for planes below ~2^28
+                       samples.  The same frame pair gives the same bits in any batch; sse is exact */
 } vqa_plane_metrics;
 
 /* ---- lifecycle ------------------------------------------------------------ */

@@ -55,6 +55,11 @@ static inline int ssim_strips(int h, long long groups /* workgroups per strip ro
     const int cap = ssim_max_strips(h);
     return ns > cap ? cap : ns;
 }
+#ifndef SSIM_FIXED_SUM
+#define SSIM_FIXED_SUM 1 // 1 (shipped): the SSIM map is summed in 2^-27 fixed point - integer sums are associative, so a plane's mean
+                         // does not depend on how the launch cut it into strips (= on the batch size); 0: measurement build, the
+                         // float / double sums of rounds 1-5 (<= 1e-8 relative apart between batch geometries)
+#endif
 #ifndef SSIM_ROWS
 #define SSIM_ROWS 8   // rows per LDS round trip of k_ssim_gauss_p2 (8 = shipped; 2, 4 = measurement builds)
 #endif
@@ -324,6 +329,7 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
     __shared__ float4 vb[NB][R][QT + 1];    // [step parity][row of the step][column]
     __shared__ double red[4];
     __shared__ unsigned long long redu[4];
+    __shared__ unsigned long long redf[4];
     const int f = blockIdx.y;
     const int t = threadIdx.x;
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
@@ -352,6 +358,14 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
     f4 acc[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) acc[s] = f4{0.f, 0.f, 0.f, 0.f};
+    // The SSIM map's sum.  Every value of the map is the same float whichever strip computes it (fixed tap order down and
+    // across); what used to follow the strip geometry - and so the batch size: ssim_strips() - was only the ORDER the values
+    // were added in (a float chain per lane, doubles per workgroup).  A lane's step yields the float sum of <= R adjacent
+    // values of one row, in column order (|sum| <= R); that is rounded ONCE to a multiple of 2^-27 and added as an integer:
+    // integer addition is associative, so lanes, workgroups and strips can be cut anywhere and k_ssim_finalize gets the
+    // same total, bit for bit.  The rounding is <= 2^-28 per R values: <= 5e-10 on the mean (the bar is 1e-4), and the
+    // integer sum carries none of the float chain's own ~1e-7 drift.
+    long long ssim_fx = 0;
     float ssim_acc = 0.f;
     uint32_t sse_acc = 0;
     float sse_sq = 0.f, sse_xy = 0.f;
@@ -422,7 +436,8 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
                 const float v = ssim_centered(o0[j], o1[j]);
                 sum += out_j[j] ? v : 0.f;
             }
-            ssim_acc += sum;
+            if (SSIM_FIXED_SUM) ssim_fx += (long long)__float2int_rn(sum * 134217728.f); // 2^27: |sum| <= 8 fits 31 bits
+            else ssim_acc += sum;
         }
     };
 
@@ -466,20 +481,33 @@ __global__ __launch_bounds__(QT) void k_ssim_gauss_p2(const uint8_t *__restrict_
         }
     }
     sse_acc += (uint32_t)(sse_sq - 2.f * sse_xy);
-    const double bs = block_sum((double)ssim_acc, red);
+    static_assert(R <= 8, "2^27 x R must fit an int");
+    const double bs = SSIM_FIXED_SUM ? 0.0 : block_sum((double)ssim_acc, red);
+    const unsigned long long bf = SSIM_FIXED_SUM ? block_sum_u64((unsigned long long)ssim_fx, redf) : 0ull; // (two's complement: signed sums wrap right)
     const unsigned long long be = block_sum_u64((unsigned long long)sse_acc, redu);
     if (t == 0) {
         const int pidx = g.plane_index[ch];
-        partials[(int64_t)pidx * partial_plane_stride + (int64_t)f * bpp + tile] = bs;
+        double *slot = &partials[(int64_t)pidx * partial_plane_stride + (int64_t)f * bpp + tile];
+        if (SSIM_FIXED_SUM) *reinterpret_cast<unsigned long long *>(slot) = bf;
+        else *slot = bs;
         if (be) atomicAdd((unsigned long long *)&res[(int64_t)f * n_planes + pidx].sse, be);
     }
 }
 
+// FIXED: the partials are 2^-27 fixed-point integer sums (k_ssim_gauss_p2), else doubles (vf_ssim kernels, lab kernels)
+template <bool FIXED>
 __global__ void k_ssim_finalize(const double *__restrict__ partials, int bpp, int n, double inv_count, int plane_index,
                                 int n_planes, vqa_plane_metrics *__restrict__ res)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
+    if (FIXED) {
+        long long s = 0;
+        const long long *p = reinterpret_cast<const long long *>(partials);
+        for (int i = 0; i < bpp; i++) s += p[(int64_t)f * bpp + i];
+        res[(int64_t)f * n_planes + plane_index].ssim = (double)s * (1.0 / 134217728.0) * inv_count; // (|s| < 2^53: exact)
+        return;
+    }
     double s = 0;
     for (int i = 0; i < bpp; i++) s += partials[(int64_t)f * bpp + i];
     res[(int64_t)f * n_planes + plane_index].ssim = s * inv_count;
@@ -540,10 +568,17 @@ void launch_quality_gauss(hipStream_t st, const uint8_t *ref, const uint8_t *dis
         break;
     }
 #undef LAUNCH_SSIM
-    for (int i = 0; i < count; i++)
-        hipLaunchKernelGGL(k_ssim_finalize, dim3((n + 63) / 64), dim3(64), 0, st,
-                           partials + (int64_t)idx[i] * partial_plane_stride, bpp, n,
-                           1.0 / ((double)(w - 10) * (double)(h - 10)), idx[i], n_planes, res);
+    const bool fixed = SSIM_FIXED_SUM && ssim_variant() == 0; // (the lab build's one-row kernels leave doubles)
+    for (int i = 0; i < count; i++) {
+        if (fixed)
+            hipLaunchKernelGGL(k_ssim_finalize<true>, dim3((n + 63) / 64), dim3(64), 0, st,
+                               partials + (int64_t)idx[i] * partial_plane_stride, bpp, n,
+                               1.0 / ((double)(w - 10) * (double)(h - 10)), idx[i], n_planes, res);
+        else
+            hipLaunchKernelGGL(k_ssim_finalize<false>, dim3((n + 63) / 64), dim3(64), 0, st,
+                               partials + (int64_t)idx[i] * partial_plane_stride, bpp, n,
+                               1.0 / ((double)(w - 10) * (double)(h - 10)), idx[i], n_planes, res);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -785,7 +820,7 @@ void launch_quality_ffmpeg(hipStream_t st, const uint8_t *ref, const uint8_t *di
         if ((w & 3) || (h & 3))
             hipLaunchKernelGGL(k_sse_ragged, dim3((n + 63) / 64), dim3(64), 0, st, ref, dist, ref_frame_stride,
                                dist_frame_stride, q.offset, q.row_stride, q.pixel_step, w, h, n, idx[i], n_planes, res);
-        hipLaunchKernelGGL(k_ssim_finalize, dim3((n + 63) / 64), dim3(64), 0, st,
+        hipLaunchKernelGGL(k_ssim_finalize<false>, dim3((n + 63) / 64), dim3(64), 0, st,
                            partials + (int64_t)idx[i] * partial_plane_stride, bpp, n,
                            1.0 / ((double)(bh - 1) * (double)(bw - 1)), idx[i], n_planes, res);
     }

@@ -276,6 +276,26 @@ def test_bind_numa_reads_the_gpus_cpus_from_sysfs_and_binds_before_any_gpu_call(
         assert bench.bind_numa(1, True, sysfs)["bound"] is False          # the GPU's CPUs are not ours (another cpuset): left alone
         assert bench.bind_numa(0, False, sysfs) == {"bound": False, "why": "--no-bind-numa"}
         assert bench.bind_numa(0, True, str(tmp_path / "nowhere"))["bound"] is False
+        os.sched_setaffinity(0, have)
+        # an unprivileged container (this pool's GPU boxes): the KFD properties are EPERM, /dev/dri holds exactly the render
+        # nodes of the container's GPUs, partition (amdgpu_xcp) nodes have no local_cpulist
+        drm = tmp_path / "box"
+        for minor, cpus in ((128, "4000-4003"), (129, None), (160, lo), (168, "%d" % have[0])):
+            d = drm / "sys" / "class" / "drm" / ("renderD%d" % minor) / "device"
+            d.mkdir(parents=True)
+            if cpus is not None:
+                (d / "local_cpulist").write_text(cpus + "\n")
+        dev = drm / "dev"
+        dev.mkdir()
+        for minor in (129, 160, 168):      # renderD128 is another tenant's: not in the container's /dev/dri
+            (dev / ("renderD%d" % minor)).write_text("")
+        cpus, src = bench.gpu_local_cpus(0, str(drm / "sys"), str(dev))
+        assert cpus == bench._parse_cpulist(lo) and "renderD160" in src
+        assert bench.gpu_local_cpus(1, str(drm / "sys"), str(dev))[0] == {have[0]}
+        none, why = bench.gpu_local_cpus(2, str(drm / "sys"), str(dev))
+        assert none is None and "kfd" in why and "drm" in why
+        rec = bench.bind_numa(0, True, str(drm / "sys"), str(dev))
+        assert rec["bound"] and "renderD160" in rec["source"]
     finally:
         os.sched_setaffinity(0, have)
 
