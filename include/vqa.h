@@ -225,6 +225,15 @@ VQA_API int vqa_free_device(vqa_ctx *ctx, void *p);
 VQA_API int vqa_copy_h2d(vqa_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 VQA_API int vqa_copy_d2h(vqa_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
 VQA_API int vqa_sync(vqa_ctx *ctx);
+/* Device-side ordering between two contexts of ONE device, no host wait: everything enqueued on `waiter`'s stream after this
+ * call starts only after everything enqueued on `signaler`'s stream BEFORE this call has completed (hipEventRecord +
+ * hipStreamWaitEvent).  What it is for: a host that feeds frames over PCIe keeps ONE context as its copy lane - all
+ * vqa_copy_h2d calls go there, so uploads cross PCIe one after another, in chunk order - and lets the context that will
+ * measure a chunk wait for it:  vqa_copy_h2d(copy_ctx, ...); vqa_stream_wait(work_ctx, copy_ctx); vqa_*_submit(work_ctx, ...).
+ * The upload of chunk k+1 then runs under the kernels of chunk k (uploads enqueued on the work contexts' own streams all
+ * start at once, share the link and finish together: the kernels wait for all of them - profiles/round6_api_trace_*.json).
+ * Both contexts are the calling thread's.  VQA_ERR_INVALID for the same ctx twice or contexts of different devices.     */
+VQA_API int vqa_stream_wait(vqa_ctx *waiter, vqa_ctx *signaler);
 /* the ctx's hipStream_t, as an opaque pointer (for event timing by the caller) */
 VQA_API void *vqa_stream(vqa_ctx *ctx);
 

@@ -103,6 +103,7 @@ SIGNATURES = {
     "vqa_copy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vqa_copy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "vqa_sync": (C.c_int, [C.c_void_p]),
+    "vqa_stream_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vqa_stream": (C.c_void_p, [C.c_void_p]),
     "vqa_complexity_submit": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, C.c_int64, C.c_uint32, C.POINTER(VqaParams)]),

@@ -46,6 +46,7 @@ struct vqa_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // VQA_OPT_OVERLAP: block-SAD, the Canny chain and the full-frame DCT on their own streams
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_xctx = nullptr;   // vqa_stream_wait: "everything enqueued on this ctx so far" for another ctx's stream to wait on
     hipEvent_t fb_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // Farneback: expansions of level k ready (0..3), planes ready (4), chunk done (5)
     std::string last_err;
     // options (vqa_set_option)
@@ -839,6 +840,7 @@ int vqa_destroy(vqa_ctx *c)
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_xctx) (void)hipEventDestroy(c->ev_xctx);
     for (int i = 0; i < 6; i++)
         if (c->fb_ev[i]) (void)hipEventDestroy(c->fb_ev[i]);
     (void)hipStreamDestroy(c->stream);
@@ -897,6 +899,17 @@ int vqa_copy_h2d(vqa_ctx *c, void *dst, const void *src, size_t bytes)
     if (!c || !dst || !src) return VQA_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return VQA_OK;
+}
+int vqa_stream_wait(vqa_ctx *waiter, vqa_ctx *signaler)
+{
+    if (!waiter || !signaler || waiter == signaler) return VQA_ERR_INVALID;
+    if (waiter->device != signaler->device) return VQA_ERR_INVALID;
+    HIPCHK(waiter, hipSetDevice(waiter->device));
+    if (!signaler->ev_xctx) HIPCHK(waiter, hipEventCreateWithFlags(&signaler->ev_xctx, hipEventDisableTiming));
+    // the record captures the signaler's stream as it stands NOW; re-recording the event later does not move a wait already enqueued
+    HIPCHK(waiter, hipEventRecord(signaler->ev_xctx, signaler->stream));
+    HIPCHK(waiter, hipStreamWaitEvent(waiter->stream, signaler->ev_xctx, 0));
     return VQA_OK;
 }
 int vqa_copy_d2h(vqa_ctx *c, void *dst, const void *src, size_t bytes)

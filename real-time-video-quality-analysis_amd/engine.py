@@ -176,6 +176,11 @@ class Engine:
     def sync(self):
         N.check(self.lib.vqa_sync(self.ctx), "vqa_sync", self.ctx)
 
+    def wait_for(self, other):
+        """vqa_stream_wait: what is enqueued on this engine from now on starts after what `other` (an engine of the same device,
+        e.g. the pass's copy lane) has enqueued so far - a device-side dependency, the host does not wait."""
+        N.check(self.lib.vqa_stream_wait(self.ctx, other.ctx), "vqa_stream_wait", self.ctx)
+
     def drain(self):
         """Wait out whatever this engine still has pending (a quality and / or a complexity batch), discard the results and
         synchronise its streams: after a failure in the caller's loop nothing reads the caller's buffers any more and the

@@ -18,9 +18,12 @@ read it there.  Where the frames come from decides how they travel:
     pageable  ordinary NumPy arrays / np.load(mmap_mode="r"): copier threads move chunk k+1 into a slot of a
               pinned ring (np.copyto releases the GIL) while chunk k crosses PCIe and chunk k-1 is on the GPU
 
-Chunks alternate between two engines (= two HIP streams with their own scratch) on the device, so the copy of one
-chunk overlaps the kernels of the other and the host-side float tails (tails.py) of a finished chunk run while
-the GPU works on the next.  Nothing here computes a metric: pointers in, records out.
+Every upload of a pass goes through the device's COPY LANE (get_copy_engine: one more engine, whose stream carries nothing
+but H2D copies), so chunks cross PCIe one after another, in order; chunks alternate between two measuring engines (= two
+HIP streams with their own scratch), each of which waits ON THE DEVICE for its chunk's upload (vqa_stream_wait).  The
+upload of chunk k+1 therefore runs under the kernels of chunk k, the copiers gather chunk k+2 meanwhile, and the host-side
+float tails (tails.py) of a finished chunk run while the GPU works on the next.  Nothing here computes a metric: pointers
+in, records out.
 """
 import os
 import threading
@@ -48,6 +51,7 @@ MASK = {"dct": N.M_DCT, "temporal": N.M_TEMPORAL_DCT, "hist": N.M_GRAY_HIST, "co
 
 _engines = {}
 _second = {}
+_copy = {}
 _staging = {}
 _lock = threading.RLock()
 
@@ -75,6 +79,19 @@ def get_engine_lanes(device=None, count=2):
 
 def get_engine_pair(device=None):
     return get_engine_lanes(device, 2)
+
+
+def get_copy_engine(device=None):
+    """The device's COPY LANE: an engine that never measures anything - every upload of a pass is enqueued on its stream, so
+    chunks cross PCIe one after another, in order, and the engine that measures a chunk waits for it on the device
+    (Engine.wait_for = vqa_stream_wait).  Uploads enqueued on the measuring engines' own streams all start at once, share the
+    link and finish together, and every chunk's kernels wait for all of them: rocprofv3 showed 1.4 % of the H2D time under a
+    kernel that way (profiles/round6_api_trace_pinned.json, "before")."""
+    first = get_engine(device)
+    with _lock:
+        if first.device not in _copy:
+            _copy[first.device] = Engine(first.device)
+        return _copy[first.device]
 
 
 class _Staging:
@@ -152,7 +169,7 @@ def release_buffers(device=None):
         with pass_lock(d):
             with _lock:
                 st = _staging.pop(d, None)
-                engs = ([_engines[d]] if d in _engines else []) + list(_second.get(d, ()))
+                engs = ([_engines[d]] if d in _engines else []) + list(_second.get(d, ())) + ([_copy[d]] if d in _copy else [])
             if st is not None:
                 st.release()
             for e in engs:
@@ -472,20 +489,24 @@ def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series
     else:
         lanes = list(get_engine_lanes(first.device, min(MAX_LANES, nchunks)))
     st = _staging_of(first) if host else None
+    cp = get_copy_engine(first.device) if host else None   # the copy lane: every upload of the pass, in chunk order
+    nb = len(lanes) + 1    # buffer sets on the device: the chunks the lanes hold + the one whose upload runs under their kernels
     params = first.make_params(resize=complexity.resize, dct_mode=complexity.dct_mode,
                                motion_mode=complexity.motion_mode) if want_c else None
-    # ---- buffers: every host feed gets a buffer per lane (slot 0 of the complexity stream is the halo, the frame before the
+    # ---- buffers: every host feed gets a buffer per set (slot 0 of the complexity stream is the halo, the frame before the
     # chunk's first sample), every staged feed a region of each ring slot
     off = 0
     for f in feeds.values():
         f.slots = max([slot + cnt for p in plans for slot, _s, cnt, _t in p.get(f.key, ())] or [0])
         if f.host and f.slots:
-            for ln in range(len(lanes)):
-                st.device_buffer(ln, f.name, f.slots * f.fb)
+            for bs in range(min(nb, nchunks)):
+                st.device_buffer(bs, f.name, f.slots * f.fb)
         if f.staged:
             f.ring_off = off
             off += f.slots * f.fb
-    ring = st.ring(len(lanes) + 1, off) if staged else None
+    # ring slots: the chunks the lanes hold (a slot is free again when its chunk has been waited for), the chunk being
+    # uploaded and the chunk the copiers gather meanwhile
+    ring = st.ring(min(len(lanes) + 2, nchunks), off) if staged else None
     free_slots = list(range(len(ring))) if staged else None
     fills = []  # every copier future of the pass that may still be running
 
@@ -511,21 +532,31 @@ def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series
             p["fill"] = futs
             fills.extend(futs)
 
-    def submit(p, eng):
-        ln = p["k"] % len(lanes)
+    def upload(p):
+        """the chunk's frames onto the copy lane, behind the previous chunk's (buffer set k mod nb: the chunk that used it
+        last has been waited for)"""
+        p["dev"] = {}
+        if not host:
+            return
+        bs = p["k"] % nb
         if p.get("fill"):
-            with N.trace_range("vqa:gather-wait chunk=%d lane=%d", p["k"], ln):
+            with N.trace_range("vqa:gather-wait chunk=%d", p["k"]):
                 for f in p["fill"]:
                     f.result()
                 fills[:] = [f for f in fills if not f.done()]
-        dev = {}
-        with N.trace_range("vqa:upload chunk=%d lane=%d", p["k"], ln):
+        with N.trace_range("vqa:upload chunk=%d set=%d", p["k"], bs):
             for f in feeds.values():
                 if f.host and f.slots and p[f.key]:
-                    dev[f.name] = st.device_buffer(ln, f.name, f.slots * f.fb)
-                    _upload(eng, dev[f.name].ptr, f.fb, p[f.key], p.get("ring", {}).get(f.name))
+                    p["dev"][f.name] = st.device_buffer(bs, f.name, f.slots * f.fb)
+                    _upload(cp, p["dev"][f.name].ptr, f.fb, p[f.key], p.get("ring", {}).get(f.name))
+
+    def submit(p, eng):
+        ln = p["k"] % len(lanes)
+        dev = p["dev"]
         p["has_q"] = p["has_c"] = False
         with N.trace_range("vqa:submit chunk=%d lane=%d", p["k"], ln):
+            if host:
+                eng.wait_for(cp)   # on the device: the lane's stream continues when the uploads enqueued so far are done
             if want_q:
                 fq, fr = feeds["qdist" if split else "dist"], feeds["ref"]
                 pair = []
@@ -591,22 +622,33 @@ def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series
                     series["temporal"].extend(tails.as_list("temporal", v))
                     arrays["temporal"].append(v)
 
+    # The loop.  Uploads run one chunk ahead of the kernels and gathers one chunk ahead of the uploads: while the lanes hold
+    # chunks k-L+1 .. k, chunk k+1 crosses PCIe (copy lane) and the copiers gather chunk k+2 into the ring.  A finished
+    # chunk's host work (tails, stats lines) runs last in an iteration, when the device has everything it can have.
     pending = []
     try:
-        nxt = plan(0)
-        start_fill(nxt)
+        cur = plan(0)
+        start_fill(cur)
+        upload(cur)
+        ahead = None
+        if nchunks > 1:
+            ahead = plan(1)
+            start_fill(ahead)
         for k in range(nchunks):
-            p, eng = nxt, lanes[k % len(lanes)]
+            p, eng = cur, lanes[k % len(lanes)]
             done = None
             if len(pending) == len(lanes):
                 done = pending.pop(0)[0]
                 wait(done, eng)          # (the oldest pending chunk ran on this very lane)
-            if k + 1 < nchunks:  # the copiers work on chunk k + 1 while chunk k is enqueued and runs
-                nxt = plan(k + 1)
-                start_fill(nxt)
             submit(p, eng)
             pending.append((p, eng))
-            if done is not None:         # the lane is busy again: now the finished chunk's host work
+            if k + 1 < nchunks:
+                cur = ahead
+                upload(cur)
+                if k + 2 < nchunks:
+                    ahead = plan(k + 2)
+                    start_fill(ahead)
+            if done is not None:
                 finish(done)
         while pending:
             p, eng = pending.pop(0)
@@ -618,7 +660,7 @@ def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series
                 f.result()
             except BaseException:
                 pass
-        _abandon(lanes)
+        _abandon(lanes + ([cp] if cp is not None else []))
         raise
     q = (np.concatenate(sse), np.concatenate(ssim)) if want_q else None
     if want_c:

@@ -111,24 +111,24 @@ def main():
         per_q.setdefault(q, []).append((a, b))
     out["per_queue_kernel_busy_ms"] = {q: ms(total(clip(iv, calls))) for q, iv in sorted(per_q.items())}
     # per lane (stream.py's roctx ranges): host time inside each stage, and the lane's device-side idle = from the end of
-    # a chunk's wait to the start of the lane's next upload
+    # a chunk's wait to the start of the lane's next submit
     stage = {}
     lane_wait_end, lane_gap = {}, {}
     for a, b, name in sorted(M):
-        m = re.match(r"vqa:([a-z-]+) chunk=(\d+)(?: lane=(\d+))?", name)
+        m = re.match(r"vqa:([a-z-]+) chunk=(\d+)(?: (?:lane|set)=(\d+))?", name)
         if not m or not intersect([[a, b]], calls):
             continue
         st, lane = m.group(1), m.group(3)
         stage.setdefault(st, []).append(b - a)
-        if lane is not None:
-            if st == "upload" and lane in lane_wait_end:
+        if lane is not None and st in ("submit", "wait"):
+            if st == "submit" and lane in lane_wait_end:
                 lane_gap.setdefault(lane, []).append(a - lane_wait_end.pop(lane))
             if st == "wait":
                 lane_wait_end[lane] = b
     out["host_stage_ms"] = {k: {"count": len(v), "total": ms(sum(v)), "mean": ms(sum(v) / len(v))} for k, v in sorted(stage.items())}
     out["lane_turnaround_ms"] = {("lane %s" % k): {"count": len(v), "mean": ms(sum(v) / len(v)), "max": ms(max(v))}
                                  for k, v in sorted(lane_gap.items())}
-    out["lane_turnaround_what"] = "host time from the end of a lane's wait(chunk k) to the start of its next upload(chunk k + lanes): the lane's engine has nothing enqueued meanwhile"
+    out["lane_turnaround_what"] = "host time from the end of a lane's wait(chunk k) to the start of its next submit(chunk k + lanes): the lane's engine has nothing enqueued meanwhile"
     # the dominant kernels inside the calls
     per_k = {}
     for a, b, name, _ in K:
