@@ -1,8 +1,9 @@
 /* vqa_stream.c — the one-pass pipeline (the host side that real-time-video-quality-analysis_amd/stream.py is for the
  * Python surface) from plain C against include/vqa.h alone: a clip of reference / encoded frames in ORDINARY (pageable)
  * host memory is cut into chunks; copier threads gather chunk k+1 into a slot of a three-slot pinned ring while chunk k
- * crosses PCIe (vqa_copy_h2d: a true DMA from pinned memory) and chunk k-1 is on the GPU; chunks alternate between two
- * contexts (two HIP streams), each chunk is uploaded ONCE and serves both the quality kernels (every frame,
+ * crosses PCIe (vqa_copy_h2d on a third context, the copy lane: a true DMA from pinned memory, uploads in chunk order) and
+ * chunk k-1 is on the GPU; chunks alternate between two contexts (two HIP streams) that wait for their upload on the device
+ * (vqa_stream_wait), each chunk is uploaded ONCE and serves both the quality kernels (every frame,
  * video_processing.py:216) and the complexity kernels (every interval-th frame, a strided device view of the same bytes,
  * video_processing.py:242 / complexity_metrics.py:103-104).
  *
@@ -74,8 +75,9 @@ int main(int argc, char **argv)
     if (n < 1 || h < 16 || w < 16 || iv < 1 || chunk < 1 || threads < 1) { fprintf(stderr, "bad arguments\n"); return 2; }
     if (vqa_abi_version() != VQA_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 2; }
     const size_t fb = (size_t)h * w * 3;
-    vqa_ctx *ctx[LANES] = {NULL, NULL};
+    vqa_ctx *ctx[LANES] = {NULL, NULL}, *cp = NULL;         /* cp: the copy lane - its stream carries nothing but uploads */
     for (int l = 0; l < LANES; l++) { CHECK(vqa_create(0, &ctx[l])); g_err_ctx = ctx[l]; }
+    CHECK(vqa_create(0, &cp));
 
     /* the clip, as a caller that decoded two files holds it: malloc'ed.  Frame t shows pattern (t / iv) % 2, so selected
      * frames alternate between two pictures; encoded = reference + 1 */
@@ -154,13 +156,17 @@ int main(int argc, char **argv)
             } while (k == nchunks && npend > 0);
         }
         if (k == nchunks) break;
-        /* 3. upload once, submit both halves on this lane's stream */
+        /* 3. upload once - on the COPY LANE, so uploads cross PCIe one after another in chunk order instead of sharing the
+         *    link with the other lane's - and submit both halves on this lane's stream, which waits for the upload on the
+         *    device (vqa_stream_wait: no host wait) */
         const int l = k % LANES;
-        g_err_ctx = ctx[l];
+        g_err_ctx = cp;
         uint8_t *d = dev[l], *s = ring[slot];
         const int halo = j1 > j0 && (j0 + 1) * iv - 1 < a;
-        CHECK(vqa_copy_h2d(ctx[l], d + (halo ? 0 : fb), s + (halo ? 0 : fb), fb * (size_t)(b - a + (halo ? 1 : 0))));
-        CHECK(vqa_copy_h2d(ctx[l], d + enc_bytes, s + enc_bytes, fb * (size_t)(b - a)));
+        CHECK(vqa_copy_h2d(cp, d + (halo ? 0 : fb), s + (halo ? 0 : fb), fb * (size_t)(b - a + (halo ? 1 : 0))));
+        CHECK(vqa_copy_h2d(cp, d + enc_bytes, s + enc_bytes, fb * (size_t)(b - a)));
+        g_err_ctx = ctx[l];
+        CHECK(vqa_stream_wait(ctx[l], cp));
         CHECK(vqa_quality_submit(ctx[l], d + enc_bytes, d + fb, VQA_MEM_DEVICE, b - a, (int64_t)fb, (int64_t)fb, planes, 3, VQA_SSIM_GAUSS));
         if (j1 > j0) {
             const int first = (j0 + 2) * iv - 1 - a, prev = (j0 + 1) * iv - 1 - a; /* positions inside the chunk (prev < 0: the halo slot) */
@@ -194,6 +200,7 @@ int main(int argc, char **argv)
     for (int l = 0; l < LANES; l++) { g_err_ctx = ctx[l]; CHECK(vqa_trim(ctx[l])); CHECK(vqa_free_device(ctx[l], dev[l])); }
     for (int s = 0; s < SLOTS; s++) CHECK(vqa_free_pinned(ctx[0], ring[s]));
     for (int l = 0; l < LANES; l++) CHECK(vqa_destroy(ctx[l]));
+    CHECK(vqa_destroy(cp));
     free(fm); free(pm); free(ref); free(enc);
     if (bad) { fprintf(stderr, "%d self-checks failed\n", bad); return 1; }
     puts("vqa_stream ok");

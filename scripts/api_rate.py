@@ -3,6 +3,9 @@ of every interval-th, ONE pass) on a 1080p clip that lives in HBM, in pinned hos
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("VQA_BIND_NUMA", "1") != "0":   # before any GPU call: this process, its copier threads and its pinned pages next to the GPU
+    from rtvqa_amd.affinity import bind_numa
+    print("cpu affinity:", bind_numa(int(os.environ.get("VQA_DEVICE", "0"))), flush=True)
 from rtvqa_amd import complexity_metrics as cm, synth, video_processing as vp, stream
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 257

@@ -13,6 +13,9 @@ import os, sys, tempfile, time
 os.environ.setdefault("VQA_ROCTX", "1")   # markers on (a no-op without a marker library / profiler)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("VQA_BIND_NUMA", "1") != "0":   # before any GPU call: this process, its copier threads and its pinned pages next to the GPU
+    from rtvqa_amd.affinity import bind_numa
+    print("cpu affinity:", bind_numa(int(os.environ.get("VQA_DEVICE", "0"))), flush=True)
 from rtvqa_amd import _native as N
 from rtvqa_amd import complexity_metrics as cm, synth, video_processing as vp
 
