@@ -36,12 +36,14 @@ from . import tails
 from .engine import DeviceBuffer, DeviceFrames, Engine
 from .pooling import shard_range
 
-# A chunk is at most batch_size frames and at most this many bytes (all streams together) on the device.  Chunks that go through
-# the pinned ring are smaller: the first chunk's gather overlaps nothing, so short chunks start the pipeline sooner (measured on
-# 300 x 1080p pairs, frames/s at 64 / 128 / 256 / 512 / 1024 MiB - pageable: 4006 / 4137 / 4145 / 4075 / 3790, config.json's
-# interval 10: 3591 / 3748 / 3932 / 4041 / 3865; pinned, no gather: 3735 / 3970 / 4054 / 4064 / 4036 and 3756 / 3934 / 4056 / 4171 / 4194)
-CHUNK_BYTES_MAX = 1 << 30
-STAGED_CHUNK_BYTES_MAX = 384 << 20
+# A chunk is at most batch_size frames and, when it travels over PCIe, at most this many bytes (all streams together).  With the
+# copy lane (round 6) the link is busy from the first chunk's upload to the last one's, so what a chunk size still decides is the
+# exposed tail - the last chunk's kernels run after the link has gone quiet - against the per-chunk host time.  Measured on 257 x
+# 1080p pairs, frames/s at 64 / 128 / 160 / 256 / 512 / 1024 MiB - pinned: 3911 / 4144 / 4209 / 4296 / 4290 / 4246; pageable (the
+# first gather overlaps nothing, so short chunks also start the pipeline sooner): 3873 / 3790 / 4090 / 4147 / 3997 / 3753
+# (round 5, uploads on the lanes' own streams: pinned best at 1 GiB with 4064, pageable at 160-384 MiB with 4173)
+CHUNK_BYTES_MAX = 256 << 20
+STAGED_CHUNK_BYTES_MAX = 256 << 20
 STAGE_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))  # copier threads of the pinned ring
 MAX_LANES = 2                 # engines a pass alternates its chunks between (1: everything on the default engine, in order)
 

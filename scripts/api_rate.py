@@ -64,7 +64,7 @@ for mb in (64, 128, 160, 256, 512, 1024):
             best = min(best, time.perf_counter() - t0)
         out.append("%s %6.0f" % (name, n / best))
     print("chunk cap %4d MiB (both streams): %s frames/s" % (mb, "  ".join(out)), flush=True)
-stream.CHUNK_BYTES_MAX, stream.STAGED_CHUNK_BYTES_MAX = 1 << 30, 384 << 20
+stream.CHUNK_BYTES_MAX, stream.STAGED_CHUNK_BYTES_MAX = 256 << 20, 256 << 20
 for th in (1, 2, 4, 8, 12):
     stream.STAGE_THREADS = th
     cm.release_buffers()

@@ -311,3 +311,36 @@ def test_a_clip_that_only_starts_in_registered_memory_is_not_dma_ed_from():
         _same_series(cm.complexity_series(buf, 64, 48, 2, batch_size=4), cm.complexity_series(clip, 64, 48, 2, batch_size=4))
     finally:
         assert int(rt.cudaHostUnregister(buf.ctypes.data)) == 0
+
+
+def test_stream_wait_orders_a_measuring_context_behind_the_copy_lane():
+    """vqa_stream_wait (include/vqa.h): uploads enqueued on one context (the copy lane), kernels on another that waits for
+    them ON THE DEVICE.  The device buffer is overwritten with a different clip every round and measured at once, with no
+    host wait in between: a kernel that started before its upload had landed would measure the previous clip."""
+    import rtvqa_amd
+    from rtvqa_amd import _native as N
+    from rtvqa_amd.engine import DeviceBuffer, DeviceFrames
+    n, h, w = 24, 360, 640
+    clips = [_clip(n, h, w, seed=200 + k) for k in range(4)]
+    with rtvqa_amd.Engine(0) as work, rtvqa_amd.Engine(0) as cp:
+        want = [work.complexity(c[1:], prev0=c[0], mask=N.M_GRAY_HIST | N.M_EDGE | N.M_DCT, dct_mode=N.DCT_BLOCK8) for c in clips]
+        pins = []
+        for c in clips:
+            p = cp.alloc_pinned(c.shape)
+            p[...] = c
+            pins.append(p)
+        buf = DeviceBuffer(work, clips[0].nbytes)
+        fr = DeviceFrames(buf.ptr, n, h, w, owner=buf)
+        for rnd in range(12):
+            k = rnd % len(clips)
+            cp.h2d_async(buf.ptr, pins[k].ctypes.data, pins[k].nbytes)
+            work.wait_for(cp)
+            got = work.complexity(fr.slice(1, n), prev0=fr.frame(0), mask=N.M_GRAY_HIST | N.M_EDGE | N.M_DCT, dct_mode=N.DCT_BLOCK8)
+            cp.wait_for(work)      # (and the other way round: the next upload must not overtake this round's kernels)
+            for f in ("hist_gray", "edge_count", "dct_energy", "sum_gray2"):
+                assert np.array_equal(got[f], want[k][f]), (rnd, f)
+        st = work.lib.vqa_stream_wait(work.ctx, work.ctx)
+        assert st == N.VQA_ERR_INVALID and work.lib.vqa_stream_wait(work.ctx, None) == N.VQA_ERR_INVALID
+        for p in pins:
+            cp.free_pinned(p)
+        buf.free()
