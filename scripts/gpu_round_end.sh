@@ -4,9 +4,10 @@
 #           so the bench lines of part 2 carry the traffic measured on the same sources - COPY the *_pmc.json files of part 1
 #           into profiles/ (scripts/collect_profiles.sh) before starting part 2.
 #   part 2: the bench lines + rocprofv3 --kernel-trace --stats of every workload, then the clock / power trace.
-# usage (from the repo root, on the GPU box): bash scripts/gpu_round_end.sh <round tag> <1|2>
+# usage (from the repo root, on the GPU box): VQA_GIT_SHA=<git rev-parse --short HEAD of the COMMITTED tree> bash scripts/gpu_round_end.sh <round tag> <1|2>
+# (the box has no .git: without VQA_GIT_SHA the PMC files are stamped "uncommitted" - round 5's slip)
 set -o pipefail
-R=${1:-round5}
+R=${1:-round6}
 PART=${2:-1}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out
@@ -26,6 +27,7 @@ if [ "$PART" = "1" ]; then
 else
   bash scripts/gpu_profile.sh final_c3 --steps 10 --warmup 2 || exit 1
   bash scripts/gpu_profile.sh final_c1 --workload c1 --steps 5 --warmup 1 || exit 1
+  bash scripts/gpu_profile.sh final_c1ref --workload c1ref --steps 5 --warmup 1 || exit 1
   bash scripts/gpu_profile.sh final_c2 --workload c2 --steps 10 --warmup 2 --cpu-sample 32 || exit 1
   bash scripts/gpu_profile.sh final_c4 --workload c4 --steps 5 --warmup 2 --cpu-sample 8 || exit 1
   bash scripts/gpu_profile.sh final_c3ref --workload c3ref --steps 10 --warmup 2 --cpu-sample 8 || exit 1
