@@ -1,6 +1,7 @@
 """Differential soak of the one-pass host side (stream.run): random clip length / geometry / frame_interval / chunk size /
-residence (pageable, pinned, region of interest, memmap, device) and random halves (quality only, complexity only, fused) -
-every combination must return the bits of the one-chunk, one-engine pass over a contiguous copy of the clip.
+residence (pageable, pinned, region of interest, memmap, device) and random halves (quality only, complexity only, fused, and the
+split pass: a planar yuv420p quality pair next to the BGR stream, each in its own place) - every combination must return the bits
+of the one-chunk, one-engine pass over a contiguous copy of the clip.
 usage: python scripts/fuzz_stream.py [n_cases] [seed0]   (needs a GPU; exits non-zero on the first difference)"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -75,6 +76,40 @@ for case in range(n_cases):
                 got = vp.frame_quality(x, y, lay, mode, hh, ww, batch_size=batch)
                 assert np.array_equal(got[0], one[0]) and np.array_equal(got[1], one[1]), ("layout", lay, mode, (case, n, hh, ww, batch))
             eng.free_pinned(pa); eng.free_pinned(pb)
+    if case % 3 == 0 and min(h, w) >= 16:
+        # the SPLIT pass (the reference's own quantities: a planar yuv420p quality pair next to the encoded BGR stream, round 6):
+        # the three streams in three random places, chunked, against the two halves run alone in one chunk each
+        from rtvqa_amd import _native as N_, frames as fr_
+        from rtvqa_amd.engine import DeviceFrames, yuv420p_planes
+        ya, yb = fr_.bgr_to_yuv420p(ref), fr_.bgr_to_yuv420p(dist)
+        ypl = yuv420p_planes(h, w)
+        smode = N_.SSIM_FFMPEG if (case // 3) % 2 or min((h + 1) // 2, (w + 1) // 2) < 11 else N_.SSIM_GAUSS
+        cxs = stream.Complexity((rw, rh), iv)
+        one_q, _ = stream.run(yb, ya, stream.Quality(ypl, smode), batch_size=10 ** 6, engine=eng)
+        _, one_s = stream.run(dist, complexity=cxs, batch_size=10 ** 6, engine=eng)
+        held, pins = [], []
+
+        def place(arr, planar, where):
+            if where == 0:
+                return arr
+            if where == 1:
+                pp = eng.alloc_pinned(arr.shape)
+                pp[...] = arr
+                pins.append(pp)
+                return pp
+            d = eng.upload(arr.reshape(n, 1, -1) if planar else arr)
+            held.append(d)
+            return DeviceFrames(d.ptr, n, h, w, frame_stride=arr.shape[1], row_stride=w, owner=d, channels=1) if planar else d
+        wq = int(r.integers(0, 3))   # (the quality pair shares a residence class: device with device)
+        xs = place(dist, False, int(r.integers(0, 3))), place(ya, True, wq), place(yb, True, wq if wq == 2 else int(r.integers(0, 2)))
+        got_q, got_s = stream.run(xs[0], xs[1], stream.Quality(ypl, smode), cxs, batch_size=batch, qdist=xs[2])
+        assert np.array_equal(got_q[0], one_q[0]) and np.array_equal(got_q[1], one_q[1]), ("split quality", ctx)
+        for k in KINDS:
+            assert len(got_s[k]) == len(one_s[k]) and all((x == y) or (x != x and y != y) for x, y in zip(got_s[k], one_s[k])), ("split", k, ctx)
+        for pp in pins:
+            eng.free_pinned(pp)
+        for d in held:
+            d._owner.free()
     for p in keep:
         eng.free_pinned(p)
     if res == 4:

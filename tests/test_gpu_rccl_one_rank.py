@@ -29,7 +29,7 @@ def _env():
     return e
 
 
-@pytest.mark.parametrize("workload,extra", [("c3", ["--batch", "8"]), ("c1", ["--batch", "30"])])
+@pytest.mark.parametrize("workload,extra", [("c3", ["--batch", "8"]), ("c1", ["--batch", "30"]), ("c1ref", ["--batch", "30"])])
 def test_bench_runs_its_rccl_path_with_one_rank(workload, extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--dist-always", "--workload", workload, "--steps", "2",
@@ -41,6 +41,23 @@ def test_bench_runs_its_rccl_path_with_one_rank(workload, extra):
     assert cfg["backend"] == "nccl" and cfg["rccl_ranks"] == 1 and cfg["collective"] == "rccl scalar all-reduce", cfg
     assert cfg["devices"] == [0] and line["n_gpus"] == 1 and line["value"] > 0
     assert line["verified"]["ok"] is True
+    assert cfg["cpu_affinity"]["bound"] in (True, False) and cfg["launched_by"] == "torch.distributed.run"
+    if workload == "c1ref":
+        assert (cfg["ssim_mode"], cfg["pixfmt"], cfg["motion"]) == ("ffmpeg", "yuv420p", "farneback")
+
+
+def test_bench_gpus_1_needs_no_launcher_and_binds_to_the_gpus_cpus():
+    """the driver's N = 1 command, plainly; the rank is pinned to the CPUs of its GPU's NUMA node before any GPU call when sysfs
+    tells which those are (this pool's boxes: through the render node the container holds)"""
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--batch", "8", "--steps", "2", "--warmup", "1", "--cpu-sample", "0",
+           "--e2e-steps", "2", "--e2e-batch", "8", "--api-steps", "0"]
+    r = subprocess.run(cmd, cwd=REPO, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2500:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    aff = line["config"]["cpu_affinity"]
+    assert line["n_gpus"] == 1 and line["config"]["launched_by"] == "direct" and line["verified"]["ok"] is True
+    assert aff["bound"] is True and aff["cpus"] >= 1 and "local_cpulist" in aff["source"], aff
+    assert line["end_to_end"]["fps"] > 0 and "copy lane" in line["end_to_end"]["overlap"]
 
 
 _SHARDED = (
