@@ -8,9 +8,8 @@ sharded across GPUs can be pooled with one scalar all-reduce.
 import numpy as np
 
 
-def smooth_data(data, alpha=0.8):
-    """pandas ewm(alpha, adjust=True).mean():  y_t = sum_i (1-a)^i x_{t-i} / sum_i (1-a)^i."""
-    x = np.asarray(data, dtype=np.float64).reshape(-1)
+def _smooth_loop(x, alpha):
+    """the recurrence as pandas runs it: num_t = num_{t-1} (1-a) + x_t, den_t = den_{t-1} (1-a) + 1, y_t = num_t / den_t"""
     out = []
     num = 0.0
     den = 0.0
@@ -20,6 +19,38 @@ def smooth_data(data, alpha=0.8):
         den = den * decay + 1.0
         out.append(num / den)
     return np.array(out, dtype=np.float64)
+
+
+_TAPS = {}
+
+
+def _taps(alpha):
+    """(1-a)^i for as many i as a double can see next to (1-a)^0 (2^-60 relative), and their running sums; None when the
+    decay is too slow for a short window (then the loop runs)"""
+    if alpha not in _TAPS:
+        decay = 1.0 - alpha
+        k = 1
+        if decay > 0.0:
+            k = int(np.ceil(-60.0 * np.log(2.0) / np.log(decay))) + 1 if decay < 1.0 else 1 << 30
+        _TAPS[alpha] = None if k > 96 else (decay ** np.arange(k, dtype=np.float64), np.cumsum(decay ** np.arange(k, dtype=np.float64)))
+    return _TAPS[alpha]
+
+
+def smooth_data(data, alpha=0.8):
+    """pandas ewm(alpha, adjust=True).mean():  y_t = sum_i (1-a)^i x_{t-i} / sum_i (1-a)^i.
+    For the reference's alpha (0.8: the 27th tap is below 2^-60) the sum is formed as written - one short convolution,
+    the same value as the recurrence to ~1e-16 relative - instead of a Python loop per sample (0.27 of the 0.5 ms the
+    entry point's pooling took per call); slow decays, short series and series with non-finite samples take the loop."""
+    x = np.asarray(data, dtype=np.float64).reshape(-1)
+    taps = _taps(alpha) if 0.0 < alpha <= 1.0 else None
+    if taps is None or x.size < 16 or not np.isfinite(x).all():
+        return _smooth_loop(x, alpha)
+    w, cs = taps
+    num = np.convolve(x, w)[:x.size]
+    den = np.full(x.size, cs[-1])
+    m = min(x.size, cs.size)
+    den[:m] = cs[:m]
+    return num / den
 
 
 def pooled_mean(data, alpha=0.8):

@@ -120,3 +120,25 @@ def test_fast9_score_matches_oracle(shim):
                     assert shim.shim_fast9_score(int(g[y, x]), ring, thr) == sc[y, x], (y, x, thr)
             corners += int((sc > 0).sum())
     assert corners > 50
+
+
+def test_smooth_data_window_form_equals_the_recurrence():
+    """pooling.smooth_data forms pandas' adjusted EWM as one short convolution for fast decays (the reference's alpha 0.8) and
+    as the recurrence otherwise: both are the same sum, to the last bits (the golden fixtures of the real smooth_data pin it to
+    1e-13; here the two forms against each other, every size class, scale and decay)."""
+    import numpy as np
+    from rtvqa_amd import pooling
+    rng = np.random.default_rng(7)
+    for T in (0, 1, 15, 16, 17, 27, 28, 100, 256, 3000):
+        for scale in (1.0, 1e9, 1e-6):
+            for alpha in (0.8, 0.5, 0.35, 0.9, 1.0, 0.05):
+                x = rng.random(T) * scale - 0.25 * scale
+                y, z = pooling.smooth_data(x, alpha), pooling._smooth_loop(np.asarray(x, np.float64), alpha)
+                assert y.shape == z.shape == (T,)
+                assert np.allclose(y, z, rtol=4e-15, atol=2e-16 * scale), (T, scale, alpha)   # (signed samples cancel: absolute bar)
+    # a non-finite sample keeps the recurrence's behaviour (everything after it is NaN), whatever the length
+    x = rng.random(64)
+    x[20] = np.nan
+    y = pooling.smooth_data(x, 0.8)
+    assert np.isfinite(y[:20]).all() and np.isnan(y[20:]).all()
+    assert pooling._taps(0.05) is None and pooling._taps(0.8)[0].size < 40
