@@ -357,9 +357,8 @@ def complexity_series(video, resize_width, resize_height, frame_interval=10, bat
     that range only and out["range"] = (lo, hi) gives its place in the whole series.
     motion: "sad" / "farneback" (None: set_motion_mode's / VQA_MOTION's choice); device: the GPU of a host clip's pass
     (None: VQA_DEVICE, else LOCAL_RANK, else 0) - the config keys of the same names.
-    Chunks of up to batch_size samples alternate between two engines of the device (one with Farneback motion: its
-    scratch is GiB-sized per context); only the selected frames of a host clip cross PCIe, from the caller's pinned
-    memory or through the pinned ring."""
+    Chunks of up to batch_size samples alternate between two engines of the device; only the selected frames of a host clip
+    cross PCIe (through the copy lane), from the caller's pinned memory or through the pinned ring."""
     cx = stream.Complexity((resize_width, resize_height), frame_interval, mask, dct_mode, motion_mode_of(motion), shard)
     return stream.run(_open_frames(video), complexity=cx, batch_size=batch_size, engine=engine, device=device)[1]
 

@@ -42,10 +42,15 @@ from .pooling import shard_range
 # 1080p pairs, frames/s at 64 / 128 / 160 / 256 / 512 / 1024 MiB - pinned: 3911 / 4144 / 4209 / 4296 / 4290 / 4246; pageable (the
 # first gather overlaps nothing, so short chunks also start the pipeline sooner): 3873 / 3790 / 4090 / 4147 / 3997 / 3753
 # (round 5, uploads on the lanes' own streams: pinned best at 1 GiB with 4064, pageable at 160-384 MiB with 4173)
-CHUNK_BYTES_MAX = 256 << 20
-STAGED_CHUNK_BYTES_MAX = 256 << 20
+CHUNK_BYTES_MAX = int(os.environ.get("VQA_CHUNK_MIB", "256")) << 20
+STAGED_CHUNK_BYTES_MAX = int(os.environ.get("VQA_CHUNK_MIB", "256")) << 20
 STAGE_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))  # copier threads of the pinned ring
 MAX_LANES = 2                 # engines a pass alternates its chunks between (1: everything on the default engine, in order)
+# measuring engines of a pass with Farneback motion.  Rounds 3-5 kept ONE (GiB-sized scratch per context, and two 64-frame
+# batches in flight thrashed in round 3); with chunks of <= 256 MiB the scratch is 1-3 GB per context and the second engine hides
+# the host time of a Farneback submit (~60 launches) behind the other chunk's kernels - c3ref's clip through the entry point, 1 / 2
+# engines: resident 4.65-4.80 k / 4.71-4.75 k, pinned host 2.45-2.48 k / 2.93 k, pageable 2.17-2.20 k / 2.65-2.67 k frames/s
+FARNEBACK_LANES = int(os.environ.get("VQA_FARNEBACK_LANES", "2"))
 
 KINDS = ("motion", "dct", "hist", "edge", "orb", "color")
 MASK = {"dct": N.M_DCT, "temporal": N.M_TEMPORAL_DCT, "hist": N.M_GRAY_HIST, "color": N.M_COLOR_HIST,
@@ -486,10 +491,11 @@ def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series
     nchunks = len(plans)
     # ---- lanes
     farneback = want_c and (complexity.mask & N.M_MOTION) and complexity.motion_mode == N.MOTION_FARNEBACK
-    if engine is not None or nchunks <= 1 or farneback or MAX_LANES < 2:
-        lanes = [first]  # (Farneback keeps GiB-sized scratch per context and fills the chip on its own: one context)
+    want_lanes = min(MAX_LANES, FARNEBACK_LANES) if farneback else MAX_LANES
+    if engine is not None or nchunks <= 1 or want_lanes < 2:
+        lanes = [first]
     else:
-        lanes = list(get_engine_lanes(first.device, min(MAX_LANES, nchunks)))
+        lanes = list(get_engine_lanes(first.device, min(want_lanes, nchunks)))
     st = _staging_of(first) if host else None
     cp = get_copy_engine(first.device) if host else None   # the copy lane: every upload of the pass, in chunk order
     nb = len(lanes) + 1    # buffer sets on the device: the chunks the lanes hold + the one whose upload runs under their kernels
