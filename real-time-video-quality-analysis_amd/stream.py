@@ -42,8 +42,13 @@ from .pooling import shard_range
 # 1080p pairs, frames/s at 64 / 128 / 160 / 256 / 512 / 1024 MiB - pinned: 3911 / 4144 / 4209 / 4296 / 4290 / 4246; pageable (the
 # first gather overlaps nothing, so short chunks also start the pipeline sooner): 3873 / 3790 / 4090 / 4147 / 3997 / 3753
 # (round 5, uploads on the lanes' own streams: pinned best at 1 GiB with 4064, pageable at 160-384 MiB with 4173)
+# Big frames: a chunk is also at least CHUNK_FRAMES_MIN frames (while that stays below CHUNK_BYTES_HARD) - per-chunk host time is
+# per chunk, not per byte: 65 x 2160p pairs (49.8 MB each), same caps - pinned: 728 / 880 / 945 / 999 / 1052 / 1070, pageable:
+# 718 / 862 / 918 / 961 / 972 / 939 (256 MiB is 5 such pairs; 16 of them are 796 MB)
 CHUNK_BYTES_MAX = int(os.environ.get("VQA_CHUNK_MIB", "256")) << 20
 STAGED_CHUNK_BYTES_MAX = int(os.environ.get("VQA_CHUNK_MIB", "256")) << 20
+CHUNK_FRAMES_MIN = 16
+CHUNK_BYTES_HARD = 1 << 30
 STAGE_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))  # copier threads of the pinned ring
 MAX_LANES = 2                 # engines a pass alternates its chunks between (1: everything on the default engine, in order)
 # measuring engines of a pass with Farneback motion.  Rounds 3-5 kept ONE (GiB-sized scratch per context, and two 64-frame
@@ -486,7 +491,8 @@ def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series
     host = any(f.host for f in feeds.values())
     staged = any(f.staged for f in feeds.values())
     limit = STAGED_CHUNK_BYTES_MAX if staged else CHUNK_BYTES_MAX
-    cap = max(1, min(int(batch_size), limit // max(per_frame, 1) if host else int(batch_size)))
+    by_bytes = max(limit // max(per_frame, 1), min(CHUNK_FRAMES_MIN, CHUNK_BYTES_HARD // max(per_frame, 1)))
+    cap = max(1, min(int(batch_size), by_bytes if host else int(batch_size)))
     plans = plan_chunks(n, want_q, interval, lo, hi, cap, split)
     nchunks = len(plans)
     # ---- lanes

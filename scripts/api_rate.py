@@ -9,7 +9,7 @@ if os.environ.get("VQA_BIND_NUMA", "1") != "0":   # before any GPU call: this pr
 from rtvqa_amd import complexity_metrics as cm, synth, video_processing as vp, stream
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 257
-h, w = 1080, 1920
+h, w = int(os.environ.get("API_H", "1080")), int(os.environ.get("API_W", "1920"))
 interval = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rs = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (w, h)
 eng = cm.get_engine()
