@@ -261,52 +261,84 @@ def process_in_batches(frames, process_func, num_workers, batch_size=100, **kwar
 
 def _batched_map(eng, kind, frames, process_func, batch_size, kw, kwargs):
     """process_in_batches' kernel branch: every chunk is ONE pinned buffer (gathered by the copier threads), ONE asynchronous
-    upload, ONE launch - and while chunk k crosses PCIe and runs, the copiers gather chunk k + 1 into the ring's other slot."""
-    results = []
+    upload, ONE launch, in the pipeline of stream.run: uploads go through the device's copy lane (in chunk order), chunks
+    alternate between two measuring engines that wait for their upload on the device - while chunk k runs, chunk k + 1
+    crosses PCIe and the copiers gather chunk k + 2 into the ring."""
     resize = None if kind in ("orb", "motion") else (kw["resize_width"], kw["resize_height"])
     params = eng.make_params(resize=resize, motion_mode=_motion_mode)
     call = functools.partial(process_func, **kwargs)
     chunks = [_chunk_job(kind, frames[i:i + batch_size], call) for i in range(0, len(frames), batch_size)]
-    # the ring's two slots are sized ONCE for the largest chunk (a slot is never re-allocated while its neighbour is in flight)
-    slot_bytes = max([sum(int(f.nbytes) for f in c["items"]) for c in chunks if c["items"]] or [0])
-    fills = []  # copier futures that may still be writing into the ring
-
-    def start(k):
-        c = chunks[k]
+    out = [None] * len(chunks)
+    # chunks that cannot be one launch (frames of different sizes: per-item map; a chunk of None pairs: zeros) first, while
+    # the default engine is idle; results keep their place
+    for k, c in enumerate(chunks):
         if not c["items"]:
-            return None
-        arr, futs = stream.stage_frames_start(eng, c["items"], slot=k & 1, slots=2, min_bytes=slot_bytes)
+            out[k] = c["finish"](None)
+    order = [k for k, c in enumerate(chunks) if c["items"]]
+    if not order:
+        return [v for part in out for v in part]
+    lanes = list(stream.get_engine_lanes(eng.device, 2)) if len(order) > 1 and stream.MAX_LANES > 1 else [eng]
+    cp = stream.get_copy_engine(eng.device)
+    st = stream._staging_of(eng)
+    nb, nslots = len(lanes) + 1, min(len(lanes) + 2, len(order))
+    # ring slots and buffer sets are sized ONCE for the largest chunk (a slot is never re-allocated while another is in flight)
+    slot_bytes = max(sum(int(f.nbytes) for f in chunks[k]["items"]) for k in order)
+    fills = []      # copier futures that may still be writing into the ring
+    gathered = {}
+
+    def gather(i):
+        arr, futs = stream.stage_frames_start(eng, chunks[order[i]]["items"], slot=i % nslots, slots=nslots, min_bytes=slot_bytes)
         fills.extend(futs)
-        return arr, futs
+        gathered[i] = (arr, futs)
+
+    def upload(i):
+        arr, futs = gathered.pop(i)
+        for f in futs:
+            f.result()
+        fills[:] = [f for f in fills if not f.done()]
+        buf = st.device_buffer(i % nb, "pib", slot_bytes)
+        cp.h2d_async(buf.ptr, arr.ctypes.data, arr.nbytes)
+        return buf, arr.shape
+
+    def submit(i, up):
+        lane = lanes[i % len(lanes)]
+        buf, (n, h, w, _c) = up
+        lane.wait_for(cp)   # on the device: the lane continues when the uploads enqueued so far have landed
+        fr = DeviceFrames(buf.ptr, n, h, w, owner=buf)
+        if chunks[order[i]]["prev0"]:
+            lane.complexity_submit(fr.slice(1, n), fr.frame(0), _MASK[kind], params)
+        else:
+            lane.complexity_submit(fr, None, _MASK[kind], params)
+
+    def wait(i):
+        k = order[i]
+        out[k] = chunks[k]["finish"](lanes[i % len(lanes)].complexity_wait())
 
     try:
-        nxt = start(0) if chunks else None
-        for k, c in enumerate(chunks):
-            cur = nxt
-            if cur is None:  # nothing to launch (frames of different sizes: per-item map; a chunk of None pairs: zeros)
-                results.extend(c["finish"](None))
-                nxt = start(k + 1) if k + 1 < len(chunks) else None
-                continue
-            arr, futs = cur
-            for f in futs:
-                f.result()
-            fills[:] = [f for f in fills if not f.done()]
-            if c["prev0"]:
-                eng.complexity_submit(arr[1:], arr[0], _MASK[kind], params)
-            else:
-                eng.complexity_submit(arr, None, _MASK[kind], params)
-            nxt = start(k + 1) if k + 1 < len(chunks) else None
-            rec = eng.complexity_wait()
-            results.extend(c["finish"](rec))
+        gather(0)
+        up = upload(0)
+        if len(order) > 1:
+            gather(1)
+        for i in range(len(order)):
+            if i >= len(lanes):
+                wait(i - len(lanes))    # frees the lane, the buffer set chunk i + 1 goes into and the ring slot of chunk i + 2
+            submit(i, up)
+            if i + 1 < len(order):
+                up = upload(i + 1)
+                if i + 2 < len(order):
+                    gather(i + 2)
+        for i in range(max(len(order) - len(lanes), 0), len(order)):
+            wait(i)
     except BaseException:
         for f in fills:  # (every copier of this call: the ring must be quiet when the error surfaces)
             try:
                 f.result()
             except BaseException:
                 pass
-        eng.drain()
+        for lane in lanes + [cp]:
+            lane.drain()
         raise
-    return results
+    return [v for part in out for v in part]
 
 
 def _chunk_job(kind, batch, call):
