@@ -569,6 +569,36 @@ def api_end_to_end(clips, n, steps, value, e2e_fps, config, crec=None, dist_clip
     from rtvqa_amd import complexity_metrics as cm
     from rtvqa_amd import video_processing as vp
     rates, rows = api_rates(vp, cm, clips, config, steps, n)
+    # Two caller threads on the resident clip (the reference's surface is written for threaded callers, video_processing.py:25-41,
+    # :56-67): their passes take turns on the device (stream.pass_lock), one's epilogue - tails of the last chunk, log parse, pooling,
+    # CSV row - runs under the other's kernels
+    import tempfile
+    import threading
+    with tempfile.TemporaryDirectory() as tmp:
+        clip = clips["resident"]
+        kw = {"encoded_bgr": clip[2]} if len(clip) > 2 else {}
+        rows2, errs = [None, None], []
+
+        def caller(t):
+            try:
+                for _ in range(steps):
+                    rows2[t] = vp.process_video_and_extract_metrics(clip[0], clip[1], config, csv_file=os.path.join(tmp, "t.csv"), **kw)
+            except BaseException as e:  # noqa: BLE001 - reported below
+                errs.append(repr(e))
+        ts = [threading.Thread(target=caller, args=(t,)) for t in range(2)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt2 = time.perf_counter() - t0
+        with open(os.path.join(tmp, "t.csv")) as f:
+            csv_rows = sum(1 for _ in f)
+    if errs or csv_rows != 1 + 2 * steps:
+        sys.stderr.write("[bench] FATAL: two caller threads: %s, %d CSV lines\n" % (errs, csv_rows))
+        os._exit(4)
+    rates["resident_2_threads_fps"] = round(2 * steps * n / dt2, 1)
+    rows["resident_thread_0"], rows["resident_thread_1"] = rows2
     cm.release_buffers()  # the pinned ring and lane buffers of the passes: given back (stream.release_buffers)
     m = rows["resident"]
     out = dict(rates, frames_per_call=n, calls=steps, config=config,
@@ -585,6 +615,7 @@ def api_end_to_end(clips, n, steps, value, e2e_fps, config, crec=None, dist_clip
             sys.stderr.flush()
     if value:
         out["resident_vs_value"] = round(rates["resident_fps"] / value, 3)
+        out["resident_2_threads_vs_value"] = round(rates["resident_2_threads_fps"] / value, 3)
     if e2e_fps:
         out["host_pinned_vs_end_to_end"] = round(rates["host_pinned_fps"] / e2e_fps, 3)
         out["host_pageable_vs_end_to_end"] = round(rates["host_pageable_fps"] / e2e_fps, 3)
