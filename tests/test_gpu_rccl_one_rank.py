@@ -82,3 +82,25 @@ def test_sharded_aggregator_over_rccl_with_one_rank():
     e = dict(_env(), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, "-c", _SHARDED % REPO], cwd=REPO, env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARDED-RCCL-OK" in r.stdout, (r.stdout[-300:], r.stderr[-2500:])
+
+
+def test_configs4_shape_with_two_ranks_on_the_one_gpu_and_no_launcher():
+    """BASELINE configs[4] in miniature, as far as a 1-GPU box can take it: `bench.py --workload c4 --gpus 2` with NO launcher
+    starts its two ranks itself (fresh children), each runs the real 2160p suite on its own stream - here both pinned to
+    device 0 (VQA_BENCH_DEVICE: the rehearsal, scalar reductions over gloo because RCCL refuses two ranks on one device) -,
+    each verifies its last step against the oracle, and rank 0 prints ONE line for the whole job."""
+    e = dict(_env(), VQA_BENCH_DEVICE="0")
+    cmd = [sys.executable, "bench.py", "--workload", "c4", "--gpus", "2", "--batch", "4", "--steps", "2", "--warmup", "1",
+           "--cpu-sample", "0", "--e2e-steps", "0", "--api-steps", "0"]
+    r = subprocess.run(cmd, cwd=REPO, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["id"] == "c4" and cfg["rehearsal_single_device"] is True and cfg["devices"] == [0]
+    assert cfg["collective"] == "gloo scalar all-reduce" and cfg["launched_by"].startswith("bench.py itself")
+    assert line["verified"]["ok"] is True and line["verified"]["ranks"] == 2
+    frames = cfg["frames_per_step_per_gpu"] * line["steps"] * 2
+    assert abs(line["value"] - frames / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1e-3 * line["value"]
+    assert "starting 2 ranks" in r.stderr
