@@ -102,3 +102,39 @@ def test_pass_lock_is_one_reentrant_lock_per_device():
             t.start()
             t.join()
             assert held == [False]    # another thread waits
+
+
+def test_a_half_built_pinned_ring_is_given_back_whole():
+    """_Staging.ring() leaked the slots it had allocated (and kept slot_bytes bumped) when a later
+    alloc_pinned failed.  With a stand-in engine whose third allocation fails: everything allocated is freed, the ring is
+    empty, and the next call starts from scratch."""
+    from rtvqa_amd import stream
+
+    class FakeEngine:
+        device = 0
+
+        def __init__(self):
+            self.live, self.calls, self.fail_at = [], 0, 3
+
+        def alloc_pinned(self, shape):
+            self.calls += 1
+            if self.calls == self.fail_at:
+                raise MemoryError("pinned allocation failed")
+            a = np.zeros(shape, np.uint8)
+            self.live.append(id(a))
+            return a
+
+        def free_pinned(self, a):
+            self.live.remove(id(a))
+
+    eng = FakeEngine()
+    st = stream._Staging(eng)
+    with pytest.raises(MemoryError):
+        st.ring(4, 1000)
+    assert eng.live == [] and st.slots == [] and st.slot_bytes == 0
+    eng.fail_at = -1
+    slots = st.ring(4, 1000)
+    assert len(slots) == 4 and len(eng.live) == 4 and st.slot_bytes == 1000
+    assert st.ring(2, 500)[0] is slots[0] and len(eng.live) == 4          # big enough: kept
+    bigger = st.ring(3, 2000)                                              # a bigger chunk: the old slots go, new ones come
+    assert len(bigger) == 3 and len(eng.live) == 3 and st.slot_bytes == 2000
