@@ -887,8 +887,9 @@ def main_c1(args, rank, local_rank, world):
     c1_bad = False
     if rank == 0:
         P = h * w
-        nchunks = max(1, -(-n // cfg["batch_size"]))
-        fpl = float(n) / nchunks  # frame pairs per quality launch (chunks of batch_size)
+        # a chunk of the resident clip spans batch_size SAMPLES = batch_size * frame_interval source frames (stream.py)
+        nchunks = max(1, -(-n // (cfg["batch_size"] * cfg["frame_interval"])))
+        fpl = float(n) / nchunks  # frame pairs per quality launch
         pairs = max(len(cm.selected_indices(n, cfg["frame_interval"])) - 1, 0)
         if rt:
             # vf_ssim on yuv420p: three planar launches per chunk, 3P bytes in all -> P per frame and launch; Farneback: 279 B per

@@ -48,6 +48,7 @@ from .pooling import shard_range
 CHUNK_BYTES_MAX = int(os.environ.get("VQA_CHUNK_MIB", "256")) << 20
 STAGED_CHUNK_BYTES_MAX = int(os.environ.get("VQA_CHUNK_MIB", "256")) << 20
 CHUNK_FRAMES_MIN = 16
+SAMPLES_PER_CHUNK = os.environ.get("VQA_SAMPLES_PER_CHUNK", "1") != "0"   # (0: a chunk is batch_size source frames, as in round 5)
 CHUNK_BYTES_HARD = 1 << 30
 STAGE_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))  # copier threads of the pinned ring
 MAX_LANES = 2                 # engines a pass alternates its chunks between (1: everything on the default engine, in order)
@@ -492,7 +493,11 @@ def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series
     staged = any(f.staged for f in feeds.values())
     limit = STAGED_CHUNK_BYTES_MAX if staged else CHUNK_BYTES_MAX
     by_bytes = max(limit // max(per_frame, 1), min(CHUNK_FRAMES_MIN, CHUNK_BYTES_HARD // max(per_frame, 1)))
-    cap = max(1, min(int(batch_size), by_bytes if host else int(batch_size)))
+    # batch_size is the reference's: items per process_in_batches chunk = SELECTED frames (complexity_metrics.py:128, :268-290).  A
+    # chunk of a fused pass is a dense source range, so it spans batch_size * interval frames: with config.json's interval 10 a
+    # launch measures up to 100 samples, not 10 (Farneback's pyramid runs at 0.42 of HBM on 64 pairs and 0.28 on 10)
+    by_batch = int(batch_size) * (interval if (want_q and want_c and interval and interval > 1 and SAMPLES_PER_CHUNK) else 1)
+    cap = max(1, min(by_batch, by_bytes if host else by_batch))
     plans = plan_chunks(n, want_q, interval, lo, hi, cap, split)
     nchunks = len(plans)
     # ---- lanes
