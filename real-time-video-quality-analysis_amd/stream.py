@@ -45,10 +45,10 @@ from .pooling import shard_range
 # Big frames: a chunk is also at least CHUNK_FRAMES_MIN frames (while that stays below CHUNK_BYTES_HARD) - per-chunk host time is
 # per chunk, not per byte: 65 x 2160p pairs (49.8 MB each), same caps - pinned: 728 / 880 / 945 / 999 / 1052 / 1070, pageable:
 # 718 / 862 / 918 / 961 / 972 / 939 (256 MiB is 5 such pairs; 16 of them are 796 MB)
-CHUNK_BYTES_MAX = int(os.environ.get("VQA_CHUNK_MIB", "256")) << 20
-STAGED_CHUNK_BYTES_MAX = int(os.environ.get("VQA_CHUNK_MIB", "256")) << 20
+CHUNK_BYTES_MAX = 256 << 20
+STAGED_CHUNK_BYTES_MAX = 256 << 20
 CHUNK_FRAMES_MIN = 16
-SAMPLES_PER_CHUNK = os.environ.get("VQA_SAMPLES_PER_CHUNK", "1") != "0"   # (0: a chunk is batch_size source frames, as in round 5)
+SAMPLES_PER_CHUNK = True      # (False: a chunk of a fused pass is batch_size source frames, as in round 5)
 CHUNK_BYTES_HARD = 1 << 30
 STAGE_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))  # copier threads of the pinned ring
 MAX_LANES = 2                 # engines a pass alternates its chunks between (1: everything on the default engine, in order)
@@ -56,7 +56,7 @@ MAX_LANES = 2                 # engines a pass alternates its chunks between (1:
 # batches in flight thrashed in round 3); with chunks of <= 256 MiB the scratch is 1-3 GB per context and the second engine hides
 # the host time of a Farneback submit (~60 launches) behind the other chunk's kernels - c3ref's clip through the entry point, 1 / 2
 # engines: resident 4.65-4.80 k / 4.71-4.75 k, pinned host 2.45-2.48 k / 2.93 k, pageable 2.17-2.20 k / 2.65-2.67 k frames/s
-FARNEBACK_LANES = int(os.environ.get("VQA_FARNEBACK_LANES", "2"))
+FARNEBACK_LANES = 2
 
 KINDS = ("motion", "dct", "hist", "edge", "orb", "color")
 MASK = {"dct": N.M_DCT, "temporal": N.M_TEMPORAL_DCT, "hist": N.M_GRAY_HIST, "color": N.M_COLOR_HIST,
