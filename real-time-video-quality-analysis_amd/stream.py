@@ -346,6 +346,23 @@ def plan_chunks(n, want_q, interval, lo, hi, cap, split=False):
     return plans
 
 
+def chunk_frames(batch_size, fused_interval, host_bytes_per_frame, staged):
+    """Frames (complexity-only passes: samples) per chunk - pure arithmetic.
+
+    batch_size is the reference's: items per process_in_batches chunk = SELECTED frames (complexity_metrics.py:128, :268-290).  A
+    chunk of a FUSED pass (quality + complexity: fused_interval = its frame_interval, else None) is a dense source range, so it
+    spans batch_size * interval frames: with config.json's interval 10 a launch measures up to 100 samples, not 10 (Farneback's
+    pyramid runs at 0.42 of HBM on 64 pairs and 0.28 on 10).  A chunk that crosses PCIe (host_bytes_per_frame > 0: what one
+    source frame brings along, all streams together) is also at most CHUNK_BYTES_MAX (STAGED_...: through the ring) - but at
+    least CHUNK_FRAMES_MIN frames while that stays below CHUNK_BYTES_HARD."""
+    by_batch = int(batch_size) * (fused_interval if (fused_interval and fused_interval > 1 and SAMPLES_PER_CHUNK) else 1)
+    if host_bytes_per_frame <= 0:
+        return max(1, by_batch)
+    limit = STAGED_CHUNK_BYTES_MAX if staged else CHUNK_BYTES_MAX
+    by_bytes = max(limit // host_bytes_per_frame, min(CHUNK_FRAMES_MIN, CHUNK_BYTES_HARD // host_bytes_per_frame))
+    return max(1, min(by_batch, by_bytes))
+
+
 class Complexity:
     """What the complexity half of a pass measures (arguments of calculate_average_scene_complexity)."""
 
@@ -491,13 +508,7 @@ def _run_locked(first, engine, dist, ref, qd, split, quality, complexity, series
         per_frame = feeds["dist"].fb
     host = any(f.host for f in feeds.values())
     staged = any(f.staged for f in feeds.values())
-    limit = STAGED_CHUNK_BYTES_MAX if staged else CHUNK_BYTES_MAX
-    by_bytes = max(limit // max(per_frame, 1), min(CHUNK_FRAMES_MIN, CHUNK_BYTES_HARD // max(per_frame, 1)))
-    # batch_size is the reference's: items per process_in_batches chunk = SELECTED frames (complexity_metrics.py:128, :268-290).  A
-    # chunk of a fused pass is a dense source range, so it spans batch_size * interval frames: with config.json's interval 10 a
-    # launch measures up to 100 samples, not 10 (Farneback's pyramid runs at 0.42 of HBM on 64 pairs and 0.28 on 10)
-    by_batch = int(batch_size) * (interval if (want_q and want_c and interval and interval > 1 and SAMPLES_PER_CHUNK) else 1)
-    cap = max(1, min(by_batch, by_bytes if host else by_batch))
+    cap = chunk_frames(batch_size, interval if (want_q and want_c) else None, per_frame if host else 0, staged)
     plans = plan_chunks(n, want_q, interval, lo, hi, cap, split)
     nchunks = len(plans)
     # ---- lanes

@@ -95,3 +95,19 @@ def test_split_passes_move_every_byte_of_either_stream_once():
 
 def q0_le(p, f):
     return p["q0"] <= f < p["q0"] + p["qn"]
+
+
+def test_chunk_frames_follows_the_references_batch_size_and_the_link():
+    """stream.chunk_frames: batch_size counts SELECTED frames (complexity_metrics.py:128, :268-290), so a fused chunk spans
+    batch_size * interval source frames; chunks that cross PCIe are capped in bytes but hold at least 16 frames of big formats."""
+    fb = 1080 * 1920 * 3
+    assert stream.chunk_frames(100, 10, 0, False) == 1000          # config.json's defaults on a resident clip: <= 100 samples per launch
+    assert stream.chunk_frames(100, 1, 0, False) == 100 and stream.chunk_frames(100, None, 0, False) == 100
+    assert stream.chunk_frames(64, None, 0, False) == 64            # quality only
+    assert stream.chunk_frames(100, 10, 2 * fb, False) == (256 << 20) // (2 * fb) == 21     # a 1080p BGR pair from host memory
+    assert stream.chunk_frames(100, 10, 2 * fb, True) == 21
+    assert stream.chunk_frames(5, 1, 2 * fb, False) == 5            # the caller's batch_size wins when it is smaller
+    assert stream.chunk_frames(100, 1, 8 * fb, False) == 16         # 2160p pairs (49.8 MB): 256 MiB would be 5 of them
+    assert stream.chunk_frames(100, 1, 32 * fb, False) == (1 << 30) // (32 * fb) == 5      # 8K pairs: 16 of them exceed 1 GiB
+    assert stream.chunk_frames(100, 1, 4 * (1 << 30), False) == 1   # a frame larger than every cap still moves
+    assert stream.chunk_frames(100, 10, fb // 10 + 2 * (fb // 2), False) == (256 << 20) // (fb // 10 + fb)   # c1ref: planar pair + a tenth of a BGR frame
