@@ -15,7 +15,9 @@
  * no torch / numpy types.  Every function returns VQA_OK (0) or a negative
  * vqa_status; nothing throws.
  *
- * Threading: one vqa_ctx per device per host thread.  A ctx owns one HIP stream,
+ * Threading: one vqa_ctx per device per host thread (a thread may own several: two that
+ * measure alternate chunks and one that only copies, tied together by vqa_stream_wait, is
+ * the pipeline this library is built for).  A ctx owns one HIP stream,
  * its scratch planes and a pinned result staging area; it is NOT thread-safe.
  * Different contexts may be used from different threads at the same time.
  * Buffers handed to a *_submit call must stay alive and unmodified until the
@@ -41,10 +43,11 @@
  * vqa_create: VQA_OVERLAP (0 / 1) = the initial value of VQA_OPT_OVERLAP below (a
  * scheduling choice; results are identical either way).  No environment variable
  * selects a kernel or changes an arithmetic path.  (The Python binding additionally
- * honours VQA_LIB_PATH to load another build of this ABI, and VQA_DEVICE.)  A separate
+ * honours VQA_LIB_PATH to load another build of this ABI, VQA_DEVICE / LOCAL_RANK for the default
+ * device, VQA_MOTION for the default motion definition and VQA_ROCTX for roctx ranges.)  A separate
  * LAB build (`make -C csrc lab` -> lab/libvqa_hip_lab.so, vqa_build_flavour() != 0)
  * keeps superseded kernels and test seams behind VQA_*_VARIANT / VQA_COMM_FAKE_RCCL /
- * VQA_HYST_MAX_ROUNDS / VQA_FAIL_ENSURE_AT / VQA_FB_CHUNK_BYTES; it is for re-measurement and fault
+ * VQA_HYST_MAX_ROUNDS / VQA_HYST_RESCUE_MAX_ROUNDS / VQA_FAIL_ENSURE_AT / VQA_FB_CHUNK_BYTES; it is for re-measurement and fault
  * injection only and is never loaded by default.
  */
 #ifndef VQA_H
