@@ -5,7 +5,8 @@ binary decode both inputs of the quality filters (video_processing.py:284-291). 
 target image and decode is out of scope, so streams arrive already decoded:
 
   .npy          [N,H,W,3] uint8 packed BGR24 (complexity path; what cv2 would have produced)
-  .y4m          YUV4MPEG2, 8-bit C420* planar 4:2:0 (quality path: the planes FFmpeg's psnr/ssim see)
+  .y4m          YUV4MPEG2, 8-bit C420* planar 4:2:0 (quality path: the planes FFmpeg's psnr/ssim see); open_y4m maps the
+                file instead of reading it (a strided view: no host memory up front)
   .yuv / raw    headerless yuv420p with explicit width/height
 
 Frames land in (optionally pinned) host buffers the engine can DMA from.
@@ -21,22 +22,53 @@ def frame_bytes_yuv420p(h, w):
     return w * h + 2 * cw * ch
 
 
-def read_y4m(path, max_frames=None, out=None):
-    """-> (frames [N, bytes_per_frame] uint8 in Y,U,V plane order, height, width, fps)."""
+def _y4m_header(path):
+    """-> (header length in bytes, height, width, fps)"""
     with open(path, "rb") as f:
         header = f.readline()
-        if not header.startswith(b"YUV4MPEG2"):
-            raise ValueError("not a YUV4MPEG2 stream: %s" % path)
-        tok = header.decode("ascii", "replace").split()
-        w = int(next(t[1:] for t in tok if t.startswith("W")))
-        h = int(next(t[1:] for t in tok if t.startswith("H")))
-        cs = next((t[1:] for t in tok if t.startswith("C")), "420jpeg")
-        if not cs.startswith("420") or re.search(r"p1[0-6]", cs):
-            raise ValueError("only 8-bit 4:2:0 Y4M is supported (got C%s)" % cs)
-        fr = next((t[1:] for t in tok if t.startswith("F")), "30:1")
-        num, den = (int(x) for x in fr.split(":"))
-        fps = num / den if den else 0.0
-        fb = frame_bytes_yuv420p(h, w)
+    if not header.startswith(b"YUV4MPEG2"):
+        raise ValueError("not a YUV4MPEG2 stream: %s" % path)
+    tok = header.decode("ascii", "replace").split()
+    w = int(next(t[1:] for t in tok if t.startswith("W")))
+    h = int(next(t[1:] for t in tok if t.startswith("H")))
+    cs = next((t[1:] for t in tok if t.startswith("C")), "420jpeg")
+    if not cs.startswith("420") or re.search(r"p1[0-6]", cs):
+        raise ValueError("only 8-bit 4:2:0 Y4M is supported (got C%s)" % cs)
+    fr = next((t[1:] for t in tok if t.startswith("F")), "30:1")
+    num, den = (int(x) for x in fr.split(":"))
+    return len(header), h, w, (num / den if den else 0.0)
+
+
+def open_y4m(path, max_frames=None):
+    """-> (frames [N, bytes_per_frame] uint8 in Y,U,V plane order, height, width, fps) WITHOUT reading the file: a strided view
+    of a memory map (every frame sits a 6-byte FRAME line + bytes_per_frame after the previous one), so a clip of any length costs no
+    host memory up front and the pass pages in what it gathers into the pinned ring (stream.py) - the reference hands the file
+    to an ffmpeg subprocess that streams it the same way (video_processing.py:284-291).  Falls back to read_y4m (which parses
+    frame by frame) when a frame header carries parameters, i.e. the frames are not equally spaced."""
+    hl, h, w, fps = _y4m_header(path)
+    fb = frame_bytes_yuv420p(h, w)
+    size = os.path.getsize(path)
+    n = (size - hl) // (fb + 6)
+    if max_frames is not None:
+        n = min(n, max_frames)
+    if n <= 0:
+        return np.zeros((0, fb), np.uint8), h, w, fps
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    marks = np.lib.stride_tricks.as_strided(mm[hl:], shape=(n, 6), strides=(fb + 6, 1), writeable=False)
+    if not (marks == np.frombuffer(b"FRAME\n", np.uint8)).all():
+        del marks, mm
+        return read_y4m(path, max_frames)
+    frames = np.lib.stride_tricks.as_strided(mm[hl + 6:], shape=(n, fb), strides=(fb + 6, 1), writeable=False)
+    return frames, h, w, fps
+
+
+def read_y4m(path, max_frames=None, out=None):
+    """-> (frames [N, bytes_per_frame] uint8 in Y,U,V plane order, height, width, fps), read into memory frame by frame
+    (frame headers with parameters are accepted); `out`: a (pinned) array to read into."""
+    hl, h, w, fps = _y4m_header(path)
+    fb = frame_bytes_yuv420p(h, w)
+    with open(path, "rb") as f:
+        f.seek(hl)
         frames = []
         while max_frames is None or len(frames) < max_frames:
             line = f.readline()

@@ -146,8 +146,8 @@ class _StatsWriter:
 def _open_quality_stream(src, layout, height, width):
     """-> (frames, layout, height, width).  .y4m paths select the yuv420p layout by themselves."""
     if isinstance(src, str) and src.endswith(".y4m"):
-        from .frames import read_y4m
-        arr, h, w, _fps = read_y4m(src)
+        from .frames import open_y4m
+        arr, h, w, _fps = open_y4m(src)     # a memory map: the pass pages in what it gathers, nothing is read up front
         return arr, "yuv420p", h, w
     if layout == "bgr24":
         return _open_frames(src), layout, height, width

@@ -51,3 +51,46 @@ def test_config_loader_matches_reference_checks(tmp_path):
             vp.validate_config(bad)
     with pytest.raises(FileNotFoundError):
         vp.load_config(str(tmp_path / "missing.json"))
+
+
+def test_open_y4m_maps_the_file_and_equals_the_eager_reader(tmp_path):
+    """open_y4m: the clip as a strided view of a memory map (frames are a 6-byte FRAME line + bytes apart), byte-identical to what read_y4m
+    loads; a stream whose frame headers carry parameters (unequal spacing) falls back to the frame-by-frame reader."""
+    bgr = synth.s_natural(5, 36, 50, seed=2)
+    yuv = frames.bgr_to_yuv420p(bgr)
+    p = str(tmp_path / "m.y4m")
+    frames.write_y4m(p, yuv, 36, 50)
+    arr, h, w, fps = frames.open_y4m(p)
+    fb = frames.frame_bytes_yuv420p(36, 50)
+    assert (h, w, fps) == (36, 50, 30.0) and arr.shape == (5, fb) and arr.strides == (fb + 6, 1)
+    b = arr
+    while b is not None and not isinstance(b, np.memmap):
+        b = getattr(b, "base", None)
+    assert isinstance(b, np.memmap)          # a view of the mapped file, not a copy
+    assert (arr == yuv).all() and (arr == frames.read_y4m(p)[0]).all() and not arr.flags.writeable
+    assert frames.open_y4m(p, max_frames=2)[0].shape == (2, fb)
+    # a truncated last frame is not a frame
+    with open(p, "ab") as f:
+        f.write(b"FRAME\n" + bytes(10))
+    assert frames.open_y4m(p)[0].shape == (5, fb)
+    # frame headers with parameters: not equally spaced -> the parsing reader
+    q = str(tmp_path / "params.y4m")
+    with open(q, "wb") as f:
+        f.write(b"YUV4MPEG2 W50 H36 F25:1 Ip A1:1 C420jpeg\n")
+        for k in range(3):
+            f.write(b"FRAME Ip\n" if k == 1 else b"FRAME\n")
+            f.write(yuv[k].tobytes())
+    arr2, _, _, fps2 = frames.open_y4m(q)
+    assert arr2.shape == (3, fb) and (arr2 == yuv[:3]).all() and fps2 == 25.0
+    empty = str(tmp_path / "empty.y4m")
+    with open(empty, "wb") as f:
+        f.write(b"YUV4MPEG2 W50 H36 F25:1 C420\n")
+    assert frames.open_y4m(empty)[0].shape == (0, fb)
+    with pytest.raises(ValueError):
+        frames.open_y4m(str(tmp_path / "b.y4m") if (tmp_path / "b.y4m").exists() else _not_y4m(tmp_path))
+
+
+def _not_y4m(tmp_path):
+    p = tmp_path / "not.y4m"
+    p.write_bytes(b"RIFF....")
+    return str(p)
