@@ -98,11 +98,16 @@ def write_y4m(path, frames, h, w, fps=(30, 1)):
             f.write(fr.tobytes())
 
 
-def read_raw_yuv420p(path, h, w, max_frames=None):
+def read_raw_yuv420p(path, h, w, max_frames=None, mmap=True):
+    """headerless planar yuv420p -> [N, bytes_per_frame]; mapped, not read (mmap=False: loaded into memory)"""
     fb = frame_bytes_yuv420p(h, w)
     n = os.path.getsize(path) // fb
     if max_frames is not None:
         n = min(n, max_frames)
+    if n <= 0:
+        return np.zeros((0, fb), np.uint8)
+    if mmap:
+        return np.memmap(path, dtype=np.uint8, mode="r", shape=(n, fb))
     return np.fromfile(path, np.uint8, count=n * fb).reshape(n, fb)
 
 
