@@ -159,11 +159,11 @@ typedef struct vqa_frame_metrics {
                                     pixel's flow lies within float rounding of FarnebackUpdateMatrices' in-frame test
                                     (a discontinuity of the algorithm: either side is a valid evaluation; seen on
                                     35x31 / 129x34 noise frames, 4e-4 on the mean) - there 2e-3.
-                                    NOT bit-stable across batch geometry: the column sums of the last iteration restart per
-                                    strip and the strip count follows the number of pairs in the chunk, so the same frame
-                                    pair submitted in batches of different size can differ by <= 1e-6 relative (tested);
-                                    the same batch always gives the same bits.  Every other field is independent of how
-                                    frames are batched. */
+                                    Independent of how frames are batched (round 6): the running column sums of the flow
+                                    iteration restart at every multiple of 16 rows - the only rows where a row strip may
+                                    begin - and the magnitudes are summed in 2^-28 fixed point, so the strip count a launch
+                                    picks from its number of pairs changes speed, never a bit (rounds 4-5: <= 1e-6 between
+                                    batch sizes).  Every field of this record is independent of the batch. */
 } vqa_frame_metrics;
 
 /* One 8-bit plane inside a frame buffer (planar YUV plane, or one channel of

@@ -783,9 +783,13 @@ __global__ __launch_bounds__(BS_NT) void k_fb_blur_solve(const float *__restrict
 // (FI_OUT = FI_NT - 14 output columns + the 7-column halo either side) of a row strip and MARCHES down it:
 //   * thread = one column: it forms the products of the entering row (y + 7) in registers, keeps the last 16 rows of
 //     them in a register ring, and carries OpenCV's running column sum  vsum += float(M[y+7] - M[y-8])  in double -
-//     the same float difference, in the same order, as optflowgf.cpp / oracle fb_blur_solve; with one strip per frame
-//     (ns = 1) the column sums are the oracle's bit for bit, drift of the float differences included; a lower strip
-//     starts from the plain sum of its first 15 rows;
+//     the same float difference, in the same order, as optflowgf.cpp / oracle fb_blur_solve - between RESTARTS: at every
+//     output row that is a multiple of FI_RESTART (16: once per turn of the ring) below the top the sum is formed afresh as the plain sum of the 15
+//     rows in the window (they are in the ring), in ascending row order.  That is exactly what a strip that STARTS at
+//     that row gets from its priming, and strips start only at multiples of FI_RESTART - so the flow field is the same
+//     bits whatever the number of strips, i.e. whatever the number of pairs in the launch (round 6; rounds 4-5 restarted
+//     only where a strip began, so the field followed the batch size in its last bits).  Against OpenCV's whole-frame
+//     running sum the restart removes float-difference drift: ~1e-7 on the column sums, far inside the 1e-4 bar;
 //   * FI_R rows of column sums go through LDS per step; a group of FI_R lanes takes FI_R adjacent output columns of one
 //     row each: FI_R + 14 doubles -> the 15-column window sum of the first and, sliding by one column at a time, of
 //     the others ((FI_R + 14) / FI_R LDS reads and (14 + 2 (FI_R - 1)) / FI_R additions per output and channel: 4.5 and
@@ -793,14 +797,20 @@ __global__ __launch_bounds__(BS_NT) void k_fb_blur_solve(const float *__restrict
 // The horizontal window is summed left to right per group, not slid along the whole row as OpenCV does: that
 // differs at the 1e-16 level only.  Products are never written: per pixel the iteration reads 20 B (R0) + 20 B (R1,
 // gathered) + 8 B (flow) and writes 8 B.
-// grid = (ncb * ns, pairs), block = FI_NT; QS = rows per strip, a multiple of 16 (static ring slots)
+// grid = (ncb * ns, pairs), block = FI_NT; QS = rows per strip, a multiple of FI_RESTART (and so of the 16 static ring slots)
 #ifndef FI_THREADS
 #define FI_THREADS 256 // columns per workgroup (256 = shipped; 64 = measurement build: one free-running wave per workgroup)
 #endif
 constexpr int FI_NT = FI_THREADS, FI_OUT = FI_NT - 14;
 #ifndef FB_PROBE
-#define FB_PROBE 0 // measurement builds only (scripts/build_probes.sh FB_PROBE 2): 2 = no products (constant instead)
+#define FB_PROBE 0 // measurement builds only (scripts/build_probes.sh FB_PROBE 2 ..): 2 = no products (constant instead); round 6's
+                   // A/B of the batch-independent form: 3 = no restart code, 4 = magnitudes summed in double as in rounds 4-5,
+                   // 5 = both = rounds 4-5's kernel (-DFI_RESTART_ROWS=64: the first, slower form of the restart)
 #endif
+#ifndef FI_RESTART_ROWS
+#define FI_RESTART_ROWS 16 // 16 = shipped (= the 16 static ring slots: every loop iteration of the march restarts); 64: measurement build
+#endif
+constexpr int FI_RESTART = FI_RESTART_ROWS;
 #ifndef FI_ROWS
 #define FI_ROWS 2  // rows per LDS round trip (2 = shipped; 4 = measurement build: 222 VGPRs, two waves per SIMD, 1.5x slower)
 #endif
@@ -817,8 +827,9 @@ __device__ __forceinline__ constexpr int fi_row_off(int q)
 }
 
 // SRC = 0: the displacement comes from the level's flow field `fin`; SRC = 2: zero (coarsest level, fin unused).
-// MAG: the last iteration of the finest level also sums |flow| of what it stores (float magnitudes, summed in double: the
-// expression of k_fb_mag) into mag[pair][workgroup] - the separate magnitude pass re-read the whole field for that.
+// MAG: the last iteration of the finest level also sums |flow| of what it stores into mag[pair][workgroup] - the separate
+// magnitude pass re-read the whole field for that.  The float magnitudes are added in 2^-28 fixed point: integer sums are
+// associative, so the mean does not care how the field was cut into workgroups (round 6; doubles before).
 template <int SRC, bool MAG>
 __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, const float *__restrict__ fin, int h, int w,
                                                    float *__restrict__ fout, int ncb, int QS, double *__restrict__ mag)
@@ -828,8 +839,11 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
     // two buffers, alternating by step: ONE barrier per step (a step's stores go to the buffer read two steps ago, and every
     // thread passed the barrier in between only after finishing those reads; 16 / FI_R steps per loop iteration is even)
     __shared__ __align__(16) unsigned char vsb[2][5 * FI_CHB];
-    __shared__ double mag_red[FI_NT / 64];
-    double macc = 0;
+    __shared__ unsigned long long mag_red[FI_NT / 64];
+    long long macc = 0;
+#if FB_PROBE == 4 || FB_PROBE == 5
+    double maccd = 0;
+#endif
     const int t = threadIdx.x;
     const int cb = blockIdx.x % ncb, sb = blockIdx.x / ncb;
     const int x0 = cb * FI_OUT, ys = sb * QS;
@@ -880,6 +894,18 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
 #pragma unroll
             for (int q = 0; q < FI_R; q++)
                 fb_flow_at<SRC>(fp, w, xx, row_of(yb0 + i + FI_R + q), 0, 0, nullptr, nullptr, nullptr, nullptr, 0.f, dxn[q], dyn[q]);
+            if (FB_PROBE != 3 && FB_PROBE != 5 && i == 0 && base > 16 && yb0 > 0 && (yb0 & (FI_RESTART - 1)) == 0) {
+                // RESTART (workgroup-uniform): output row yb0 is a multiple of FI_RESTART inside this strip.  The ring holds the
+                // product rows yb0 - 9 .. yb0 + 6; rows yb0 - 8 .. yb0 + 6 sit in slots 8 .. 15, 0 .. 6 (slot 7, row yb0 - 9, is
+                // about to be overwritten).  Their plain sum, ascending, is what the priming of a strip starting here leaves.
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    double a = 0.;
+#pragma unroll
+                    for (int m = 0; m < 15; m++) a += (double)ring[(8 + m) & 15][c];
+                    vsum[c] = a;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < FI_R; q++) {
                 const int y = yb0 + i + q, rho = y + BS_M;
@@ -929,15 +955,22 @@ __global__ __launch_bounds__(FI_NT) void k_fb_iter(const float *__restrict__ R, 
                         const float fx = (float)((g11 * h2 - g12 * h1) * idet), fy = (float)((g22 * h1 - g12 * h2) * idet);
                         f[2 * j] = fx;
                         f[2 * j + 1] = fy;
-                        if (MAG) macc += (double)sqrtf(fx * fx + fy * fy);
+#if FB_PROBE == 4 || FB_PROBE == 5
+                        if (MAG) maccd += (double)sqrtf(fx * fx + fy * fy);
+#else
+                        if (MAG) macc += __float2ll_rn(sqrtf(fx * fx + fy * fy) * 268435456.f); // 2^28
+#endif
                     }
                 }
             }
         }
     }
+#if FB_PROBE == 4 || FB_PROBE == 5
+    macc = __double2ll_rn(maccd * 268435456.0); // (measurement build: the double chain's total, handed on in the shipped format)
+#endif
     if (MAG) {
-        const double tot = block_sum(macc, mag_red);
-        if (t == 0) mag[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+        const unsigned long long tot = block_sum_u64((unsigned long long)macc, mag_red); // (two's complement: signed sums wrap right)
+        if (t == 0) reinterpret_cast<unsigned long long *>(mag)[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
     }
 }
 
@@ -960,13 +993,22 @@ __global__ __launch_bounds__(256) void k_fb_mag(const float *__restrict__ flow, 
 }
 #endif
 
+// FIXED: the partials are 2^-28 fixed-point integer sums (the fused iteration), else doubles (the lab build's k_fb_mag)
+template <bool FIXED>
 __global__ void k_fb_mag_finalize(const double *__restrict__ partials, int nblk, int pairs, double inv_count, int first_valid,
                                   vqa_frame_metrics *__restrict__ res)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= pairs) return;
     double s = 0;
-    for (int i = 0; i < nblk; i++) s += partials[(int64_t)p * nblk + i];
+    if (FIXED) {
+        long long t = 0;
+        const long long *q = reinterpret_cast<const long long *>(partials);
+        for (int i = 0; i < nblk; i++) t += q[(int64_t)p * nblk + i];
+        s = (double)t * (1.0 / 268435456.0);
+    } else {
+        for (int i = 0; i < nblk; i++) s += partials[(int64_t)p * nblk + i];
+    }
     res[p].flow_mag_mean = (p == 0 && !first_valid) ? 0.0 : s * inv_count;
 }
 
@@ -1178,19 +1220,26 @@ void launch_fb_blur_solve(hipStream_t st, const float *M, int pairs, int h, int 
 // first iteration, as rounds 2-3 did in k_fb_update<1>, put eight dependent loads per row on the march's critical path and
 // cost more than writing the upsampled field once with k_fb_resize<2>: LAB_NOTES.md L6.)
 // workgroups per pair of launch_fb_iter at this geometry (= partials per pair of its magnitude sums)
+// most strips a frame is cut into: strips are at least 32 rows (and at least one restart period)
+static int fb_iter_strip_cap(int h)
+{
+    const int m = FI_RESTART > 32 ? FI_RESTART : 32;
+    return h / m < 1 ? 1 : (h / m > 64 ? 64 : h / m);
+}
+
 static void fb_iter_geometry(int pairs, int h, int w, int &ncb, int &ns, int &QS)
 {
     ncb = (w + FI_OUT - 1) / FI_OUT;
     // Strips.  A workgroup's march is a chain of dependent steps, so a launch costs (residency rounds) x (rows a workgroup
     // marches): the chip holds 768 of these workgroups at once (3 per CU: 160 VGPRs, 48 KB LDS).  Take the strip count
-    // that minimises rounds x (strip rows + 16 priming rows); strips are >= 32 rows.  One strip per frame - when that
-    // wins - makes the column sums follow OpenCV's whole-frame order exactly.
+    // that minimises rounds x (strip rows + 16 priming rows); strips are >= 32 rows and whole multiples of FI_RESTART rows, the rows where
+    // the column sums restart anyway - so the choice (which follows the number of pairs) changes speed, never a bit.
     ns = 1;
-    QS = (h + 15) / 16 * 16;
-    const int cap = h / 32 < 1 ? 1 : (h / 32 > 64 ? 64 : h / 32);
+    QS = (h + FI_RESTART - 1) / FI_RESTART * FI_RESTART;
+    const int cap = fb_iter_strip_cap(h);
     long long best = -1;
     for (int n = 1; n <= cap; n++) {
-        const int qs = ((h + n - 1) / n + 15) / 16 * 16, ne = (h + qs - 1) / qs;
+        const int qs = ((h + n - 1) / n + FI_RESTART - 1) / FI_RESTART * FI_RESTART, ne = (h + qs - 1) / qs;
         constexpr int RES = 768 * 256 / FI_NT; // workgroups resident at once (3 waves per SIMD)
         const long long blocks = (long long)ncb * ne * pairs, cost = ((blocks + RES - 1) / RES) * (qs + 16);
         if (best < 0 || cost < best) { best = cost; ns = ne; QS = qs; }
@@ -1200,8 +1249,7 @@ static void fb_iter_geometry(int pairs, int h, int w, int &ncb, int &ns, int &QS
 // upper bound of fb_iter_blocks over every pair count (sizes the partials buffer)
 int fb_iter_max_blocks(int h, int w)
 {
-    const int cap = h / 32 < 1 ? 1 : (h / 32 > 64 ? 64 : h / 32);
-    return (w + FI_OUT - 1) / FI_OUT * cap;
+    return (w + FI_OUT - 1) / FI_OUT * (fb_iter_strip_cap(h) + 1);
 }
 
 int fb_iter_blocks(int pairs, int h, int w)
@@ -1230,7 +1278,7 @@ void launch_fb_iter(hipStream_t st, const float *R, const float *flow, int pairs
 void launch_fb_mag_finalize(hipStream_t st, const double *partials, int nblk, int pairs, int h, int w, bool first_valid,
                             vqa_frame_metrics *res)
 {
-    hipLaunchKernelGGL(k_fb_mag_finalize, dim3((pairs + 63) / 64), dim3(64), 0, st, partials, nblk, pairs,
+    hipLaunchKernelGGL(k_fb_mag_finalize<true>, dim3((pairs + 63) / 64), dim3(64), 0, st, partials, nblk, pairs,
                        1.0 / ((double)h * (double)w), (int)first_valid, res);
 }
 
@@ -1241,7 +1289,7 @@ void launch_fb_mag(hipStream_t st, const float *flow, int pairs, int h, int w, d
                    vqa_frame_metrics *res)
 {
     hipLaunchKernelGGL(k_fb_mag, dim3(FB_MAG_BLOCKS, pairs), dim3(256), 0, st, flow, (int64_t)h * w, partials);
-    hipLaunchKernelGGL(k_fb_mag_finalize, dim3((pairs + 63) / 64), dim3(64), 0, st, partials, FB_MAG_BLOCKS, pairs,
+    hipLaunchKernelGGL(k_fb_mag_finalize<false>, dim3((pairs + 63) / 64), dim3(64), 0, st, partials, FB_MAG_BLOCKS, pairs,
                        1.0 / ((double)h * (double)w), (int)first_valid, res);
 }
 #endif

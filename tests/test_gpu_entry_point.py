@@ -84,9 +84,8 @@ def test_y4m_pair_with_encoded_bgr_is_the_reference_true_row(y4m_case):
     # the same call with the streams as arrays (pixfmt names the layout), chunked differently: the same row
     cfg2 = dict(cfg, pixfmt="yuv420p", batch_size=100)
     m2 = vp.process_video_and_extract_metrics(c["yr"], c["yd"], cfg2, csv_file=out, column_order="fixed", encoded_bgr=c["enc"])
-    for k in FIXED[1:] + ("PSNR",):
-        assert m2[k] == m[k], k
-    assert _close(m2[FIXED[0]], m[FIXED[0]], 1e-6) and m2["SSIM"] == m["SSIM"]   # (Farneback's mean follows the batch geometry, include/vqa.h; SSIM does not)
+    for k in FIXED + ("PSNR", "SSIM"):   # (neither the SSIM mean nor - since round 6 - Farneback's follows the batch geometry)
+        assert m2[k] == m[k] or (m2[k] != m2[k] and m[k] != m[k]), k
 
 
 def test_split_pass_equals_the_two_halves_run_alone_from_every_residence(y4m_case):
