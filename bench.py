@@ -536,28 +536,24 @@ def api_rates(vp, cm, clips, config, steps, frames):
 def api_rows_check(cm, rows, crec, dist_clip, motion_mode=0):
     """The rows the entry point returned, against the C ABI's own (oracle-verified) records of the same frames: the last timed
     step measured frames 1..B of the clip against frames 0..B-1 - exactly the samples of the clip at frame_interval 1 - so
-    pooling its records through the reference's tails must give the row's eight complexity values (counts and integer-derived
-    values exactly, float sums to 1e-12: the entry point launches <= 100 frames at a time, the step 256), and the three
-    residences must agree with each other to the last bit.  One exception, documented in include/vqa.h: the Farneback mean is a
-    float sum whose grouping follows the chunk geometry (<= 1e-6 relative), and host chunks are capped in bytes."""
-    from rtvqa_amd import _native as N
+    pooling its records through the reference's tails must give the row's eight complexity values (to 1e-12: the entry point
+    launches <= 100 frames at a time, the step 256 - and no record depends on that, Farneback's mean included since round 6),
+    and the rows from every residence and caller thread must agree with each other to the last bit."""
     from rtvqa_amd import tails
     series = {k: tails.scalars(k, crec, motion_mode) for k in ("motion", "dct", "hist", "edge", "orb", "color")}
     series["temporal"] = tails.scalars("temporal", crec)[1:]
     want = cm.pool_series(series, dist_clip, 1)
-    farneback = motion_mode == N.MOTION_FARNEBACK
     bad = []
     names = list(rows)
     for name in names:
         got = [rows[name][lab] for lab in API_LABELS]
         for k, (g, wv) in enumerate(zip(got, want)):
             g, wv = float(g), float(wv)
-            tol = 1e-6 if (farneback and k == 0) else 1e-12
-            if not ((g != g and wv != wv) or abs(g - wv) <= tol * max(abs(wv), 1e-300)):
+            if not ((g != g and wv != wv) or abs(g - wv) <= 1e-12 * max(abs(wv), 1e-300)):
                 bad.append("%s tuple[%d] %.17g vs %.17g" % (name, k, g, wv))
         for lab in API_LABELS + ("PSNR", "SSIM"):
             a, b = rows[name][lab], rows[names[0]][lab]
-            if a != b and not (a != a and b != b) and not (farneback and lab == API_LABELS[0] and abs(a - b) <= 1e-6 * abs(b)):
+            if a != b and not (a != a and b != b):
                 bad.append("%s differs from %s in %s" % (name, names[0], lab))
     return bad
 
@@ -609,8 +605,8 @@ def api_end_to_end(clips, n, steps, value, e2e_fps, config, crec=None, dist_clip
     if crec is not None or tbad:
         bad = tbad + (api_rows_check(cm, rows, crec, dist_clip, motion_mode) if crec is not None else [])
         out["verified"] = {"ok": not bad, "checker": "the C ABI's last timed step (itself verified against the oracle) pooled through the "
-                                                     "reference's tails: the row's eight complexity values to 1e-12 (Farneback mean 1e-6), "
-                                                     "the three residences bit for bit (Farneback mean 1e-6)"}
+                                                     "reference's tails: the row's eight complexity values to 1e-12, the three residences and "
+                                                     "two caller threads bit for bit"}
         if bad:  # (the caller prints no line and exits 4 after the ranks' final barrier: no rank is left hanging)
             sys.stderr.write("[bench] FATAL: the entry point's row differs from the C ABI's records: %s\n" % json.dumps(bad[:8]))
             sys.stderr.flush()
@@ -927,11 +923,8 @@ def main_c1(args, rank, local_rank, world):
                         if k in ("PSNR", "SSIM", "Resolution (px)")}}
         if args.api_steps > 0:
             rates, rows = api_rates(vp, cm, host_clips, cfg, args.api_steps, n)
-            # Farneback's mean is a float sum whose grouping follows the chunk geometry (include/vqa.h), and host chunks are
-            # capped in bytes where resident ones are not: that one label may differ in its last digits
-            loose = ("Advanced Motion Complexity",) if rt else ()
-            same = all(rows[k][lab] == metrics[lab] or (lab in loose and abs(rows[k][lab] - metrics[lab]) <= 1e-6 * abs(metrics[lab]))
-                       for k in rows for lab in API_LABELS + ("PSNR", "SSIM"))
+            # (host chunks are capped in bytes where resident ones are not: no record follows the chunking, Farneback's included)
+            same = all(rows[k][lab] == metrics[lab] for k in rows for lab in API_LABELS + ("PSNR", "SSIM"))
             if not same:
                 sys.stderr.write("[bench] FATAL: %s rows from host memory differ from the resident clip's row\n" % args.workload)
                 c1_bad = True
