@@ -49,9 +49,8 @@ for lanes in (1, 2, 3, 4):
         out.append("%s %6.0f" % (name, n / best))
     print("lanes %d: %s frames/s" % (lanes, "  ".join(out)), flush=True)
 stream.MAX_LANES = 2
-if os.environ.get("API_SWEEPS", "1") == "0":
-    raise SystemExit(0)
-for mb in (64, 128, 160, 256, 512, 1024):
+SWEEPS = os.environ.get("API_SWEEPS", "1") != "0"
+for mb in ((64, 128, 160, 256, 512, 1024) if SWEEPS else ()):
     stream.CHUNK_BYTES_MAX = stream.STAGED_CHUNK_BYTES_MAX = mb << 20
     cm.release_buffers()
     out = []
@@ -65,7 +64,7 @@ for mb in (64, 128, 160, 256, 512, 1024):
         out.append("%s %6.0f" % (name, n / best))
     print("chunk cap %4d MiB (both streams): %s frames/s" % (mb, "  ".join(out)), flush=True)
 stream.CHUNK_BYTES_MAX, stream.STAGED_CHUNK_BYTES_MAX = 256 << 20, 256 << 20
-for th in (1, 2, 4, 8, 12):
+for th in ((1, 2, 4, 8, 12) if SWEEPS else ()):
     stream.STAGE_THREADS = th
     cm.release_buffers()
     vp.process_video_and_extract_metrics(ref, dist, cfg, csv_file=csv)
