@@ -246,3 +246,34 @@ def test_two_threads_share_a_device(tmp_path):
                 (a == b) or (a != a and b != b) for a, b in zip(got[k][it].values(), serial[k].values())), (k, it)
     rows = list(csv.reader(open(out)))
     assert len(rows) == 1 + 4 * len(clips) and sum(r[0] == "Bitrate (kbps)" for r in rows) == 1
+
+
+def test_command_line_with_a_y4m_pair_and_the_encoded_bgr_stream(y4m_case, tmp_path, capsys):
+    """video_processing.py:300-321's CLI with decoded streams: config.json (the reference's keys + ssim_mode / motion), the .y4m
+    quality pair and --encoded-bgr; the row lands in the CSV and equals the function call's."""
+    import json
+    from rtvqa_amd import video_processing as vp
+    c = y4m_case
+    cfg = {"crf": 28, "vmaf_model_path": None, "resize_width": 64, "resize_height": 64, "frame_interval": 4, "ssim_mode": "ffmpeg",
+           "motion": "farneback"}
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(cfg))
+    out = str(tmp_path / "cli.csv")
+    assert vp.main([str(cfg_path), c["pr"], c["pd"], "--encoded-bgr", c["pe"], "--csv", out]) == 0
+    rows = list(csv.reader(open(out)))
+    assert len(rows) == 2 and rows[1][rows[0].index("CRF")] == "28"
+    want = vp.process_video_and_extract_metrics(c["pr"], c["pd"], cfg, csv_file=str(tmp_path / "f.csv"), encoded_bgr=c["enc"])
+    got = dict(zip(rows[0], rows[1]))
+    for k in ("PSNR", "SSIM", "Advanced Motion Complexity", "DCT Complexity", "Edge Detection Complexity"):
+        assert float(got[k]) == float(want[k]), k
+    # a torch tensor on the GPU as the encoded stream and pinned torch tensors as the planar pair: in place / DMA'd from
+    import torch
+    enc_t = torch.from_numpy(c["enc"]).cuda()
+    yr_t, yd_t = torch.from_numpy(c["yr"]).pin_memory(), torch.from_numpy(c["yd"]).pin_memory()
+    t = vp.process_video_and_extract_metrics(yr_t, yd_t, dict(cfg, pixfmt="yuv420p"), csv_file=str(tmp_path / "f.csv"), encoded_bgr=enc_t)
+    for k in FIXED + ("PSNR", "SSIM"):
+        assert t[k] == want[k] or (t[k] != t[k] and want[k] != want[k]), k
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(dict(cfg, ssim_mode="psnr-hvs")))
+    with pytest.raises(ValueError, match="ssim_mode must be"):
+        vp.main([str(bad), c["pr"], c["pd"], "--encoded-bgr", c["pe"]])
