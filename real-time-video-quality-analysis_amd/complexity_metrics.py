@@ -42,13 +42,17 @@ logger = logging.getLogger(__name__)
 # ---------------------------------------------------------------------------
 # frame sources (replaces validate_video_path / read_frame_pairs / extract_frame_timestamps)
 # ---------------------------------------------------------------------------
+RAW_BGR_SUFFIXES = (".bgr", ".bgr24")
+
+
 def validate_video_path(input_path):
     """complexity_metrics.py:25-35 with this build's container formats."""
     if not isinstance(input_path, str):
         raise ValueError("Invalid input path. Please provide a valid file path.")
-    if input_path.endswith((".npy",)):
+    if input_path.endswith((".npy",) + RAW_BGR_SUFFIXES):
         return "video"
-    raise ValueError("Unsupported file type. Please provide a .npy frame stack [N,H,W,3] (uint8, BGR).")
+    raise ValueError("Unsupported file type. Please provide a .npy frame stack [N,H,W,3] (uint8, BGR) or a raw .bgr24 stream "
+                     "with height and width.")
 
 
 def _from_torch(t):
@@ -62,8 +66,8 @@ def _from_torch(t):
     return t.numpy()
 
 
-def _open_frames(video):
-    """-> array-like [N,H,W,3] uint8 (np.ndarray, memmap or DeviceFrames)."""
+def _open_frames(video, height=None, width=None):
+    """-> array-like [N,H,W,3] uint8 (np.ndarray, memmap or DeviceFrames).  height / width: the geometry of a raw .bgr24 file."""
     if isinstance(video, DeviceFrames):
         return video
     if type(video).__module__.startswith("torch") and hasattr(video, "is_cuda"):
@@ -75,6 +79,11 @@ def _open_frames(video):
         if not os.path.isfile(video):
             logger.error("Error opening video file: %s", video)
             return np.zeros((0, 1, 1, 3), np.uint8)
+        if video.endswith(RAW_BGR_SUFFIXES):
+            if not height or not width:
+                raise ValueError("a raw BGR24 stream needs height and width (config keys or arguments of the same names)")
+            from .frames import open_raw_bgr24
+            return open_raw_bgr24(video, height, width)
         return np.load(video, mmap_mode="r")
     arr = video if isinstance(video, np.ndarray) else np.stack([np.asarray(f) for f in video])
     if arr.ndim != 4 or arr.shape[3] != 3 or arr.dtype != np.uint8:

@@ -7,7 +7,8 @@ target image and decode is out of scope, so streams arrive already decoded:
   .npy          [N,H,W,3] uint8 packed BGR24 (complexity path; what cv2 would have produced)
   .y4m          YUV4MPEG2, 8-bit C420* planar 4:2:0 (quality path: the planes FFmpeg's psnr/ssim see); open_y4m maps the
                 file instead of reading it (a strided view: no host memory up front)
-  .yuv / raw    headerless yuv420p with explicit width/height
+  .yuv / raw    headerless yuv420p with explicit width/height (mapped)
+  .bgr / .bgr24 headerless packed BGR24 with explicit width/height (mapped)
 
 Frames land in (optionally pinned) host buffers the engine can DMA from.
 """
@@ -109,6 +110,20 @@ def read_raw_yuv420p(path, h, w, max_frames=None, mmap=True):
     if mmap:
         return np.memmap(path, dtype=np.uint8, mode="r", shape=(n, fb))
     return np.fromfile(path, np.uint8, count=n * fb).reshape(n, fb)
+
+
+def open_raw_bgr24(path, h, w, max_frames=None):
+    """headerless packed BGR24 (`ffmpeg -f rawvideo -pix_fmt bgr24`, what cv2.VideoCapture.read yields frame by frame,
+    complexity_metrics.py:100) -> [N,H,W,3] uint8, mapped, not read"""
+    fb = int(h) * int(w) * 3
+    if fb <= 0:
+        raise ValueError("raw BGR24 streams need height and width")
+    n = os.path.getsize(path) // fb
+    if max_frames is not None:
+        n = min(n, max_frames)
+    if n <= 0:
+        return np.zeros((0, int(h), int(w), 3), np.uint8)
+    return np.memmap(path, dtype=np.uint8, mode="r", shape=(n, int(h), int(w), 3))
 
 
 def bgr_to_yuv420p(bgr):

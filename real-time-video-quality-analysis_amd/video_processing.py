@@ -144,15 +144,21 @@ class _StatsWriter:
 
 
 def _open_quality_stream(src, layout, height, width):
-    """-> (frames, layout, height, width).  .y4m paths select the yuv420p layout by themselves."""
+    """-> (frames, layout, height, width).  .y4m paths select the yuv420p layout by themselves; headerless .yuv (planar
+    yuv420p) and .bgr / .bgr24 (packed) files take their geometry from height / width."""
     if isinstance(src, str) and src.endswith(".y4m"):
         from .frames import open_y4m
         arr, h, w, _fps = open_y4m(src)     # a memory map: the pass pages in what it gathers, nothing is read up front
         return arr, "yuv420p", h, w
+    if isinstance(src, str) and src.endswith(".yuv"):
+        if not height or not width:
+            raise ValueError("a raw yuv420p stream needs height and width")
+        from .frames import read_raw_yuv420p
+        return read_raw_yuv420p(src, height, width), "yuv420p", height, width
     if layout == "bgr24":
-        return _open_frames(src), layout, height, width
+        return _open_frames(src, height, width), layout, height, width
     if isinstance(src, str):
-        raise ValueError("Unsupported file type. Please provide a .y4m (yuv420p) or .npy ([N,H,W,3] BGR) stream.")
+        raise ValueError("Unsupported file type. Please provide a .y4m / .yuv (yuv420p) or .npy / .bgr24 ([N,H,W,3] BGR) stream.")
     return src, layout, height, width
 
 
@@ -210,6 +216,10 @@ def _check_mode_keys(config):
     bs = config.get("batch_size", 100)
     if isinstance(bs, bool) or not isinstance(bs, int) or bs <= 0:
         raise ValueError("batch_size must be a positive integer.")
+    for key in ("height", "width"):   # the geometry of headerless inputs (.yuv, .bgr24)
+        v = config.get(key)
+        if v is not None and (isinstance(v, bool) or not isinstance(v, int) or v <= 0):
+            raise ValueError("height and width must be positive integers.")
 
 
 def process_video_and_extract_metrics(input_video, encoded_video, config, csv_file="video_quality_data.csv",
@@ -231,7 +241,8 @@ def process_video_and_extract_metrics(input_video, encoded_video, config, csv_fi
         batch_size, ssim_mode ("gauss" north_star's 11x11 Gaussian, default | "ffmpeg" vf_ssim's 8x8 integer windows),
         pixfmt (None: by input | "bgr24" | "yuv420p" | "gray"), dct_mode ("auto" default: full-frame up to 128x128, 8x8 blocks
         above | "block8" | "full" the reference's cv2.dct at any size), motion ("sad" north_star's block-SAD | "farneback" the
-        reference's own; default: set_motion_mode / VQA_MOTION) and device (GPU index; default VQA_DEVICE, LOCAL_RANK, 0).
+        reference's own; default: set_motion_mode / VQA_MOTION), device (GPU index; default VQA_DEVICE, LOCAL_RANK, 0) and
+        height / width (the geometry of headerless inputs: raw .yuv planar pairs, raw .bgr24 streams).
     column_order="reference" keeps the reference's unpacking of the 8-tuple (:235-242), which shifts five labels
     (SURVEY.md §3.2); "fixed" uses the tuple's true order."""
     import tempfile
@@ -247,6 +258,7 @@ def process_video_and_extract_metrics(input_video, encoded_video, config, csv_fi
     motion_mode = cm.motion_mode_of(config.get("motion"))
     device = config.get("device")
     layout = config.get("pixfmt") or "bgr24"
+    height, width = height or config.get("height"), width or config.get("width")   # (raw .yuv / .bgr24 files carry no header)
     uid = uuid.uuid4().hex
     tmp = tempfile.gettempdir()
     psnr_log, ssim_log, vmaf_log = (os.path.join(tmp, "%s_%s.log" % (k, uid)) for k in ("psnr", "ssim", "vmaf"))
@@ -261,7 +273,7 @@ def process_video_and_extract_metrics(input_video, encoded_video, config, csv_fi
             if encoded_bgr is None:
                 raise ValueError("a %s quality pair needs the encoded stream's BGR frames for the complexity half "
                                  "(complexity_metrics.py:100 reads cv2's BGR decode): pass encoded_bgr=" % layout)
-            enc, qdist = _open_frames(encoded_bgr), _host_stream(qenc)
+            enc, qdist = _open_frames(encoded_bgr, qh or height, qw or width), _host_stream(qenc)
             ref = _host_stream(ref)
         eh, ew = (enc.h, enc.w) if isinstance(enc, DeviceFrames) else (enc.shape[1], enc.shape[2])
         if qdist is None:

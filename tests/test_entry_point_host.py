@@ -66,8 +66,10 @@ def test_planar_pair_without_the_bgr_stream_is_refused_before_any_device_work(tm
         vp.process_video_and_extract_metrics(np.zeros((3, h, w, 3), np.uint8), pr, dict(GOOD), encoded_bgr=np.zeros((3, h, w, 3), np.uint8))
     with pytest.raises(ValueError, match="Unsupported file type"):
         vp.process_video_and_extract_metrics("a.mp4", "b.mp4", dict(GOOD))
-    with pytest.raises(ValueError, match="Unsupported file type"):
+    with pytest.raises(ValueError, match="needs height and width"):     # headerless planes: the geometry must be named
         vp.process_video_and_extract_metrics("a.yuv", "b.yuv", dict(GOOD, pixfmt="yuv420p"), encoded_bgr=np.zeros((3, h, w, 3), np.uint8))
+    with pytest.raises(ValueError, match="Unsupported file type"):
+        vp.process_video_and_extract_metrics("a.nv12", "b.nv12", dict(GOOD, pixfmt="yuv420p"), encoded_bgr=np.zeros((3, h, w, 3), np.uint8))
 
 
 def test_csv_writer_under_threads_writes_one_header(tmp_path):

@@ -94,3 +94,32 @@ def _not_y4m(tmp_path):
     p = tmp_path / "not.y4m"
     p.write_bytes(b"RIFF....")
     return str(p)
+
+
+def test_raw_bgr24_and_raw_yuv_are_mapped(tmp_path):
+    """headerless streams (ffmpeg -f rawvideo): packed BGR24 [N,H,W,3] and planar yuv420p, mapped with the geometry the caller
+    names; the complexity surface accepts the .bgr24 path once it knows the geometry."""
+    from rtvqa_amd import complexity_metrics as cm
+    bgr = synth.s_natural(4, 36, 50, seed=3)
+    p = str(tmp_path / "clip.bgr24")
+    bgr.tofile(p)
+    m = frames.open_raw_bgr24(p, 36, 50)
+    assert isinstance(m, np.memmap) and m.shape == (4, 36, 50, 3) and (m == bgr).all()
+    assert frames.open_raw_bgr24(p, 36, 50, max_frames=3).shape[0] == 3
+    with open(p, "ab") as f:
+        f.write(bytes(100))                                  # a truncated frame at the end is not a frame
+    assert frames.open_raw_bgr24(p, 36, 50).shape[0] == 4
+    assert (cm._open_frames(p, 36, 50) == bgr).all() and cm.validate_video_path(p) == "video"
+    with pytest.raises(ValueError, match="height and width"):
+        cm._open_frames(p)
+    yuv = frames.bgr_to_yuv420p(bgr)
+    q = str(tmp_path / "clip.yuv")
+    yuv.tofile(q)
+    arr, layout, h, w = vp._open_quality_stream(q, "bgr24", 36, 50)
+    assert layout == "yuv420p" and (h, w) == (36, 50) and isinstance(arr, np.memmap) and (arr == yuv).all()
+    with pytest.raises(ValueError, match="height and width"):
+        vp._open_quality_stream(q, "yuv420p", None, None)
+    good = {"crf": 23, "resize_width": 64, "resize_height": 64, "frame_interval": 10, "height": 36, "width": 50}
+    vp.validate_config(good)
+    with pytest.raises(ValueError, match="height and width must be positive integers"):
+        vp.validate_config(dict(good, height=0))

@@ -277,3 +277,21 @@ def test_command_line_with_a_y4m_pair_and_the_encoded_bgr_stream(y4m_case, tmp_p
     bad.write_text(json.dumps(dict(cfg, ssim_mode="psnr-hvs")))
     with pytest.raises(ValueError, match="ssim_mode must be"):
         vp.main([str(bad), c["pr"], c["pd"], "--encoded-bgr", c["pe"]])
+
+
+def test_headerless_inputs_through_the_entry_point(y4m_case, tmp_path):
+    """raw planar .yuv pair + raw packed .bgr24 stream, geometry from the config's height / width keys: the row of the .y4m / .npy call"""
+    from rtvqa_amd import video_processing as vp
+    c = y4m_case
+    pr, pd_, pe = str(tmp_path / "r.yuv"), str(tmp_path / "d.yuv"), str(tmp_path / "enc.bgr24")
+    c["yr"].tofile(pr)
+    c["yd"].tofile(pd_)
+    c["enc"].tofile(pe)
+    cfg = {"crf": 23, "resize_width": 64, "resize_height": 64, "frame_interval": 4, "ssim_mode": "ffmpeg", "height": c["h"], "width": c["w"]}
+    out = str(tmp_path / "raw.csv")
+    raw = vp.process_video_and_extract_metrics(pr, pd_, cfg, csv_file=out, encoded_bgr=pe)
+    ref = vp.process_video_and_extract_metrics(c["pr"], c["pd"], cfg, csv_file=out, encoded_bgr=c["pe"])
+    for k in FIXED + ("PSNR", "SSIM", "Resolution (px)"):
+        assert raw[k] == ref[k] or (raw[k] != raw[k] and ref[k] != ref[k]), k
+    bgr_pair = vp.process_video_and_extract_metrics(pe, pe, cfg, csv_file=out)            # a raw BGR pair: the shared pass
+    assert "PSNR" not in bgr_pair and bgr_pair["DCT Complexity"] == ref["DCT Complexity"]   # identical streams: psnr inf, no match (:160)
